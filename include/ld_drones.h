@@ -1,0 +1,223 @@
+/*
+ * ld_drones.h — C ABI of the MI355X-native batched quadcopter simulator and
+ * neuroevolution fitness evaluator (libld_drones.so, built from
+ * learning-drones_amd/csrc/ by hipcc for gfx950).
+ *
+ * The reference (mbecker12/learning-drones) is pure Python and has no FFI or
+ * plugin registry; its boundary is the object API that evolve/evolution.py
+ * consumes.  Each entry point below names the reference symbol(s) it replaces
+ * for a whole population at once.  All `path:line` cites are relative to the
+ * reference repository root.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, POD structs passed by pointer and
+ *     copied; no C++/torch types, no exceptions across the boundary.
+ *   - Every array pointer is a DEVICE pointer owned by the caller (e.g. a
+ *     PyTorch-ROCm tensor's data_ptr()); the library allocates nothing and
+ *     keeps no global state.  Structs live in HOST memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *     Kernels are enqueued and NOT synchronised; functions are re-entrant.
+ *     One population must not be stepped from two streams at once.
+ *   - Return value: LD_OK (0) or a negative ld_status; ld_strerror() names it.
+ *   - Population arrays are struct-of-arrays over the drone index (lane i of a
+ *     wavefront owns drone i):
+ *       fstate  Real[LD_F_COUNT][n]   field-major, see enum ld_ffield
+ *       istate  int32[LD_I_COUNT][n]  see enum ld_ifield
+ *       genomes Real[ceil(P/4)][n][4] gene index p of drone i lives at
+ *                                     ((p/4)*n + i)*4 + p%4, so that a lane
+ *                                     streams 16-byte words and a wavefront
+ *                                     streams 1 KiB lines.  Gene order p is the
+ *                                     reference's: layers concatenated, each the
+ *                                     row-major (n_out, n_in+1) matrix with the
+ *                                     bias in the last column
+ *                                     (evolve/brain.py:24, :45-46;
+ *                                     evolve/util.py:56-57 flatten()).
+ *     Real = float for *_f32 entry points, double for *_f64.
+ *   - The *_f64 entry points reproduce the float32 rounding points that the
+ *     reference's mixed-precision numpy code contains
+ *     (drone/quadcopter/physical_model.py:98-104,:114; geometry.py:62-69), so
+ *     they track the reference closed-loop; *_f32 is the production path.
+ */
+#ifndef LD_DRONES_H
+#define LD_DRONES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LD_ABI_VERSION 1
+#define LD_N_INPUTS 15          /* evolve/brain.py:10 n_inputs: pos, vel, angle, angle_vel, coin */
+#define LD_N_OUTPUTS 4          /* four rotor thrust fractions */
+#define LD_MAX_HIDDEN_LAYERS 4
+#define LD_MAX_WIDTH 64
+#define LD_MAX_COINS 64
+#define LD_COIN_STRIDE 5        /* x, y, z, radius, value */
+#define LD_MAX_WALLS 16
+#define LD_WALL_STRIDE 6        /* xmin, ymin, zmin, xmax, ymax, zmax */
+
+typedef enum ld_status {
+    LD_OK = 0,
+    LD_ERR_NULL = -1,           /* a required pointer is NULL */
+    LD_ERR_SPEC = -2,           /* unsupported layer spec */
+    LD_ERR_SIZE = -3,           /* n < 0, timesteps < 0, table too long ... */
+    LD_ERR_ALIGN = -4,          /* pointer not 16-byte aligned */
+    LD_ERR_HIP = -5,            /* a HIP call failed (see ld_last_hip_error) */
+    LD_ERR_NO_DEVICE = -6       /* no HIP device visible */
+} ld_status;
+
+/* Fields of fstate.  18 integrator words + 4 thrust words per drone:
+ * Drone.position/velocity/angle/angle_vel (drone/drone.py:72-75), the six
+ * Sensor.current_acceleration values (drone/sensor/sensor.py:26) and
+ * Drone.thrust (drone/drone.py:76). */
+typedef enum ld_ffield {
+    LD_F_POS = 0, LD_F_VEL = 3, LD_F_ANGLE = 6, LD_F_ANGVEL = 9,
+    LD_F_ACC = 12,              /* x, y, z, roll, pitch, yaw accelerations of the last step */
+    LD_F_THRUST = 18,
+    LD_F_COUNT = 22
+} ld_ffield;
+
+/* Fields of istate: Drone.reward / coins / flight_time+crashed (drone/drone.py:68-71). */
+typedef enum ld_ifield {
+    LD_I_REWARD = 0,
+    LD_I_COINS = 1,
+    LD_I_STATUS = 2,            /* +flight_time while flying, -flight_time once crashed */
+    LD_I_COUNT = 3
+} ld_ifield;
+
+/* Uniform physics block: QuadcopterPhysics.__init__ (drone/quadcopter/physical_model.py:37-73)
+ * fed from drone/quadcopter/parameters.py:15-35, plus the wind vector that
+ * flight/__init__.py:28 passes to every step and the integrator step of drone/drone.py:10. */
+typedef struct ld_sim_params {
+    double mass_total;          /* m_c + 4 m_m + m_p                          physical_model.py:114 */
+    double gravity_force;       /* G = g (4 m_m + m_c) + g m_p                physical_model.py:60,70 */
+    double coef_force;          /* c_f                                        parameters.py:28 */
+    double coef_moment;         /* c_m                                        parameters.py:29 */
+    double coef_wind;           /* c_w                                        parameters.py:32 */
+    double radius_motor;        /* r_m                                        parameters.py:17 */
+    double inv_inertia[3];      /* 1/Ix, 1/Iy, 1/Iz                           physical_model.py:63 */
+    double moments_payload[3];  /* x_p g m_p, y_p g m_p, 0                    physical_model.py:71-73 */
+    double wind[3];             /* wind_speed                                 parameters.py:48 */
+    double dt;                  /* Sensor.delta_t                             drone/drone.py:10 */
+} ld_sim_params;
+
+/* Episode / reward block: constants of drone/drone.py:12-17 and the bookkeeping of
+ * flight/__init__.py:39-52,79-99. */
+typedef struct ld_episode_params {
+    int32_t reward_time;        /* +2 per step    REWARD_TIME_PASSED, flight/__init__.py:43-44 */
+    int32_t reward_crashed;     /* -3000          REWARD_CRASHED */
+    int32_t reward_unstable;    /* -1             REWARD_UNSTABLE */
+    int32_t reward_distance;    /* -100 per whole metre, REWARD_COIN_DISTANCE = -100*int(d) */
+    double angle_limit;         /* pi/4           ANGLE_LIMIT */
+    double angle_vel_limit;     /* 20             ANGLE_VEL_LIMIT */
+    double z_floor;             /* crash if z <= z_floor (0)        drone/drone.py:150 */
+    double z_ceiling;           /* crash if z >  z_ceiling (80)     drone/drone.py:150 */
+    int32_t n_coins;            /* rows of the coin table (1..LD_MAX_COINS) */
+    int32_t n_walls;            /* rows of the wall table (0..LD_MAX_WALLS); build-defined extension,
+                                   objects/walls.py is empty in the reference */
+} ld_episode_params;
+
+/* Controller shape: NeuralNetwork(layer_spec) (evolve/brain.py:10-24); the output layer
+ * always has LD_N_OUTPUTS neurons and the input layer LD_N_INPUTS. */
+typedef struct ld_mlp_spec {
+    int32_t n_hidden;                        /* 1..LD_MAX_HIDDEN_LAYERS */
+    int32_t hidden[LD_MAX_HIDDEN_LAYERS];    /* widths, each 1..LD_MAX_WIDTH */
+} ld_mlp_spec;
+
+/* Per-drone result record written by ld_fly_finalize_*; this is what the ranks all-gather
+ * at generation end: the tuple fly() returns plus the Drone attributes evolution.py prints
+ * (flight/__init__.py:83-87,97-99; evolve/evolution.py:98-103). */
+typedef struct ld_fitness_record {
+    int32_t reward;             /* Drone.reward after the distance penalty */
+    int32_t flight_time;        /* Drone.flight_time */
+    int32_t coins_crashed;      /* Drone.coins | (Drone.crashed << 30) */
+    float distance_to_coin;     /* Drone.distance_to_coin */
+} ld_fitness_record;
+
+int ld_version(void);
+const char *ld_strerror(int status);
+/* Text of the last HIP error seen by the calling thread ("" if none). */
+const char *ld_last_hip_error(void);
+/* Number of visible HIP devices, or a negative ld_status. */
+int ld_device_count(void);
+
+/* drone/quadcopter/parameters.py defaults (payload_set = None, no wind, dt = 0.01). */
+int ld_sim_params_default(ld_sim_params *out);
+/* drone/drone.py:12-17 constants; n_coins = 0, n_walls = 0 (caller sets the table sizes). */
+int ld_episode_params_default(ld_episode_params *out);
+/* Fill a coin table by the rule of flight/__init__.py:25,47-52: first coin (5,5,10) r=2 value
+ * 2000, each next one at +(5, 2.5, 0) with r=1 value 1000.  HOST pointer, n_coins rows. */
+int ld_coin_chain_reference(double *coins_host, int32_t n_coins);
+
+/* Gene count P of a spec, or a negative ld_status. */
+int64_t ld_mlp_param_count(const ld_mlp_spec *spec);
+/* Number of 16-byte words per drone in the device genome layout = ceil(P/4). */
+int64_t ld_mlp_words_per_drone(const ld_mlp_spec *spec);
+
+/* Layout conversion between the reference's per-drone gene vector (row i = genes of drone i,
+ * [n][P] row-major, what Drone.controller.weights flattens to) and the device genome layout.
+ * Both pointers are device pointers; `rows` strides the [n][P] side. */
+int ld_genomes_pack_f32(const float *rows, int64_t row_stride, float *genomes, int64_t n, int64_t P, void *stream);
+int ld_genomes_unpack_f32(const float *genomes, float *rows, int64_t row_stride, int64_t n, int64_t P, void *stream);
+int ld_genomes_pack_f64(const double *rows, int64_t row_stride, double *genomes, int64_t n, int64_t P, void *stream);
+int ld_genomes_unpack_f64(const double *genomes, double *rows, int64_t row_stride, int64_t n, int64_t P, void *stream);
+
+/* Replaces Drone.reset() (drone/drone.py:177-218) for n drones: state = init_state (12 values:
+ * pos, vel, angle, angle_vel; HOST pointer, NULL = parameters.py:49-52 defaults), accelerations
+ * and thrust 0, reward/coins/flight_time 0, not crashed. */
+int ld_population_reset_f32(float *fstate, int32_t *istate, int64_t n, const double *init_state, void *stream);
+int ld_population_reset_f64(double *fstate, int32_t *istate, int64_t n, const double *init_state, void *stream);
+
+/* Replaces Drone.measure() (drone/drone.py:129-165) = QuadcopterPhysics.calculate_accelerations
+ * (physical_model.py:75-122) + 6x Sensor.measure_acceleration/velocity_verlet
+ * (sensor.py:42-49,85-93,128-149) + crash test and instability penalties, for n drones.
+ * Drones already crashed are left untouched. */
+int ld_measure_f32(const ld_sim_params *sim, const ld_episode_params *ep,
+                   float *fstate, int32_t *istate, int64_t n, void *stream);
+int ld_measure_f64(const ld_sim_params *sim, const ld_episode_params *ep,
+                   double *fstate, int32_t *istate, int64_t n, void *stream);
+
+/* Replaces NeuralNetwork.feed_forward (evolve/brain.py:41-54) for n independent genomes:
+ * inputs Real[LD_N_INPUTS][n], outputs Real[LD_N_OUTPUTS][n]. */
+int ld_mlp_forward_f32(const ld_mlp_spec *spec, const float *genomes, const float *inputs,
+                       float *outputs, int64_t n, void *stream);
+int ld_mlp_forward_f64(const ld_mlp_spec *spec, const double *genomes, const double *inputs,
+                       double *outputs, int64_t n, void *stream);
+
+/* One iteration of the loop body of fly() (flight/__init__.py:39-89) for the whole population
+ * in ONE kernel launch: airtime reward, coin test against the pre-step position and chain
+ * advance, Drone.measure, crash freeze, Drone.translate_input_to_thrust (drone/drone.py:83-86)
+ * on the post-step state.  `coins` is a device table double[n_coins][LD_COIN_STRIDE], `walls`
+ * a device table double[n_walls][LD_WALL_STRIDE] or NULL. */
+int ld_fly_step_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
+                    const double *coins, const double *walls, const float *genomes,
+                    float *fstate, int32_t *istate, int64_t n, void *stream);
+int ld_fly_step_f64(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
+                    const double *coins, const double *walls, const double *genomes,
+                    double *fstate, int32_t *istate, int64_t n, void *stream);
+
+/* The tail of fly() (flight/__init__.py:83-87,97-99): distance penalty -100*int(d) to the
+ * current coin and the result record, for every drone (crashed ones kept the position they
+ * crashed at).  Adds the penalty into istate[LD_I_REWARD]; call once per episode. */
+int ld_fly_finalize_f32(const ld_episode_params *ep, const double *coins, const float *fstate,
+                        int32_t *istate, ld_fitness_record *records, int64_t n, void *stream);
+int ld_fly_finalize_f64(const ld_episode_params *ep, const double *coins, const double *fstate,
+                        int32_t *istate, ld_fitness_record *records, double *distance_f64,
+                        int64_t n, void *stream);
+
+/* fly(drone, timesteps) for the whole population: `timesteps` fused-step launches followed by
+ * the finalize launch, all enqueued on `stream` from C (no per-step host round trip). */
+int ld_fly_rollout_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
+                       const double *coins, const double *walls, const float *genomes,
+                       float *fstate, int32_t *istate, ld_fitness_record *records,
+                       int64_t n, int32_t timesteps, void *stream);
+int ld_fly_rollout_f64(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
+                       const double *coins, const double *walls, const double *genomes,
+                       double *fstate, int32_t *istate, ld_fitness_record *records,
+                       double *distance_f64, int64_t n, int32_t timesteps, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LD_DRONES_H */

@@ -1,0 +1,57 @@
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+GOLDEN = REPO / "tests" / "golden"
+if str(REPO) not in sys.path:
+    sys.path.insert(0, str(REPO))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(GOLDEN / name, allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure), built on demand."""
+    from oracle import oracle as O
+    O.build()
+    O.set_dot_variant(0)
+    return O
+
+
+@pytest.fixture(scope="session")
+def g1():
+    return load_golden("g1_step.npz")
+
+
+@pytest.fixture(scope="session")
+def g2():
+    return load_golden("g2_mlp.npz")
+
+
+@pytest.fixture(scope="session")
+def g3():
+    return load_golden("g3_episodes.npz")
+
+
+@pytest.fixture(scope="session")
+def g4():
+    return load_golden("g4_pid.npz")
+
+
+@pytest.fixture(scope="session")
+def g5():
+    return load_golden("g5_events.npz")
+
+
+@pytest.fixture(scope="session")
+def g6():
+    return load_golden("g6_ga.npz")

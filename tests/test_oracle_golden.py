@@ -1,0 +1,172 @@
+"""L0 of the parity ladder: the CPU oracle against golden vectors produced by the imported
+reference (tests/golden/make_golden.py).  This is what pins the oracle; everything the GPU
+tests assert is relative to it."""
+import numpy as np
+import pytest
+
+from learning_drones_amd.params import EpisodeParams, MlpSpec, SimParams
+
+# Episode 27 of G3 passes within ~1e-9 rad of the cos(pitch)=0 singularity of
+# translational_matrix (geometry.py:62-69); ulp-level libm differences (numpy's tan/exp are not
+# glibc's) are amplified there by >1e9, so only its prefix and its integer outcome are compared.
+CHAOTIC = {27: 150}
+
+
+def relerr(a, b, floor=1e-3):
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))
+
+
+def test_one_step_bit_exact(oracle, g1):
+    sim, ep = SimParams.reference(), EpisodeParams.reference()
+    n = 1500                                       # the no-wind block
+    s, a, r, c = oracle.measure(sim, ep, g1["state_in"][:n], g1["acc_in"][:n], g1["thrust"][:n])
+    assert (r == g1["reward_delta"][:n]).all()
+    assert (c == g1["crashed"][:n]).all()
+    assert c.sum() >= 5 and (r < 0).sum() > 500    # the vectors do exercise crash + penalties
+    assert np.array_equal(s, g1["state_out"][:n])                  # positions/velocities bit-exact
+    assert (a == g1["acc_out"][:n]).mean() > 0.999                 # accelerations: <=1 ulp on a handful
+    assert relerr(a, g1["acc_out"][:n], 1e-300) < 1e-14
+
+
+def test_dot_variant_pinned(oracle, g1):
+    """The BLAS summation orders restated in ld_oracle.c are what makes the step bit-exact."""
+    sim, ep = SimParams.reference(), EpisodeParams.reference()
+    n = 600
+    try:
+        oracle.set_dot_variant(1)
+        _, a_plain, _, _ = oracle.measure(sim, ep, g1["state_in"][:n], g1["acc_in"][:n], g1["thrust"][:n])
+    finally:
+        oracle.set_dot_variant(0)
+    _, a_pinned, _, _ = oracle.measure(sim, ep, g1["state_in"][:n], g1["acc_in"][:n], g1["thrust"][:n])
+    assert (a_plain == g1["acc_out"][:n]).all(axis=1).mean() < 0.5
+    assert (a_pinned == g1["acc_out"][:n]).all(axis=1).mean() > 0.995
+    assert relerr(a_plain, g1["acc_out"][:n], 1e-300) < 1e-12      # still the same function
+
+
+def test_one_step_wind(oracle, g1):
+    ep = EpisodeParams.reference()
+    for i in range(1500, 2000):
+        sim = SimParams.reference(wind=g1["wind"][i])
+        s, a, r, c = oracle.measure(sim, ep, g1["state_in"][i:i + 1], g1["acc_in"][i:i + 1], g1["thrust"][i:i + 1])
+        assert np.array_equal(s[0], g1["state_out"][i]) and np.array_equal(a[0], g1["acc_out"][i])
+        assert r[0] == g1["reward_delta"][i] and c[0] == g1["crashed"][i]
+
+
+def test_payload_physics(oracle, g1):
+    pp = g1["payload_params"]
+    sim = SimParams.reference(mass_payload=pp[0], x_payload=pp[1], y_payload=pp[2], I_x=pp[3], I_y=pp[4], I_z=pp[5])
+    for i in range(len(g1["payload_angle"])):
+        sim.wind[:] = list(g1["payload_wind"][i])
+        lin, rot = oracle.accelerations(sim, g1["payload_angle"][i], g1["payload_thrust"][i])
+        assert np.array_equal(lin[0], g1["payload_lin_acc"][i])
+        assert np.array_equal(rot[0], g1["payload_rot_acc"][i])
+
+
+def test_closed_forms_agree_with_reference_step(oracle, g1):
+    """The closed-form accelerations (what the f32 kernel computes) are the same function."""
+    sim, ep = SimParams.reference(), EpisodeParams.reference()
+    n = 1500
+    ang = np.abs(g1["state_in"][:n, 7])
+    tame = np.abs(np.cos(ang)) > 0.05              # away from the tan(pitch) pole
+    s64, a64, _, _ = oracle.measure(sim, ep, g1["state_in"][:n], g1["acc_in"][:n], g1["thrust"][:n], mode=oracle.CLOSED_F64)
+    # reference rounds forces to float32: 6e-8 relative on the linear accelerations
+    assert relerr(a64[tame], g1["acc_out"][:n][tame], 1e-2) < 2e-5
+    s32, a32, r32, c32 = oracle.measure(sim, ep, g1["state_in"][:n], g1["acc_in"][:n], g1["thrust"][:n], mode=oracle.CLOSED_F32)
+    assert relerr(s32[:, :9], g1["state_out"][:n, :9], 1e-3) < 1e-4    # north_star rtol
+    # accelerations are sums of cancelling terms; SURVEY 7.3-1 measured <= 4.9e-4 for float32
+    assert relerr(a32[tame], g1["acc_out"][:n][tame], 1.0) < 1e-3
+
+
+def test_mlp_forward(oracle, g2):
+    for si in range(int(g2["n_specs"])):
+        spec = MlpSpec.from_hidden(g2[f"hidden_{si}"])
+        assert spec.param_count == g2[f"weights_{si}"].size
+        y = oracle.mlp_forward(spec, g2[f"weights_{si}"], g2[f"x_{si}"])
+        ref = g2[f"y_{si}"]
+        assert relerr(y, ref, 1e-300) < 1e-12
+        sat = ref[1:4]                              # saturating inputs: exact 0 / 1 (brain.py:38)
+        assert np.array_equal(y[1:4][(sat == 0) | (sat == 1)], sat[(sat == 0) | (sat == 1)])
+        y32 = oracle.mlp_forward(spec, g2[f"weights_{si}"].astype(np.float32), g2[f"x_{si}"][4:].astype(np.float32),
+                                 mode=oracle.CLOSED_F32)
+        assert np.max(np.abs(y32 - ref[4:])) < 2e-4
+
+
+def test_closed_loop_episodes(oracle, g3):
+    sim, ep = SimParams.reference(), EpisodeParams.reference()
+    kinds = set()
+    for ei in range(int(g3["n_episodes"])):
+        spec = MlpSpec.from_hidden(g3[f"hidden_{ei}"])
+        T = int(g3[f"timesteps_{ei}"])
+        r = oracle.fly(sim, ep, spec, g3[f"weights_{ei}"][None], T, trace=True)
+        fin = g3[f"final_{ei}"]
+        # integer outcome of fly(): exact
+        assert int(r.reward[0]) == int(fin[0])
+        assert (int(r.coins[0]), int(r.flight_time[0]), int(r.crashed[0])) == (int(fin[2]), int(fin[3]), int(fin[4]))
+        nrun = len(g3[f"reward_{ei}"])
+        assert nrun == int(fin[3])
+        assert np.array_equal(r.trace_reward[:nrun, 0], g3[f"reward_{ei}"])       # reward after every step
+        assert np.array_equal(r.trace_coins[:nrun, 0], g3[f"coins_{ei}"])
+        steps = g3[f"steps_{ei}"]
+        ref = np.concatenate([g3[f"state_{ei}"], g3[f"acc_{ei}"], g3[f"thrust_{ei}"]], axis=1)
+        got = r.trace_state[steps, 0, :]
+        if ei in CHAOTIC:
+            keep = steps < CHAOTIC[ei]
+            got, ref = got[keep], ref[keep]
+            assert abs(r.distance[0] - fin[5]) < 0.05
+        else:
+            assert abs(r.distance[0] - fin[5]) < 1e-9
+        assert relerr(got, ref) < 1e-8, f"episode {ei}"
+        kinds.add((str(g3[f"kind_{ei}"]), int(fin[2]) > 0, bool(fin[4])))
+    # the set covers crashes, full flights and coin collection
+    assert ("random", False, True) in kinds and ("hover", True, False) in kinds
+
+
+def test_reward_events(oracle, g5):
+    sim, ep = SimParams.reference(), EpisodeParams.reference()
+    spec = MlpSpec.from_hidden(g5["hidden"])
+    genes = np.zeros((1, spec.param_count))
+    for i in range(len(g5["init"])):
+        r = oracle.fly(sim, ep, spec, genes, int(g5["timesteps"][i]), init_state=g5["init"][i])
+        fin = g5["final"][i]
+        got = (int(r.reward[0]), int(r.coins[0]), int(r.flight_time[0]), int(r.crashed[0]))
+        assert got == (int(fin[0]), int(fin[2]), int(fin[3]), int(fin[4])), f"event case {i}"
+        assert abs(r.distance[0] - fin[5]) < 1e-12
+        assert np.allclose(r.state[0], g5["state_final"][i], rtol=0, atol=1e-13)
+
+
+def test_pid_episodes_config1(oracle, g4):
+    sim = SimParams.reference()
+    names = list(g4["paramset_names"])
+    for name in ("00", "11", "22"):
+        gains = g4["paramsets"][names.index(name)]
+        ts, tu, tsc, ttg, score = oracle.pid_episode(sim, gains, g4["coins"], 1600)
+        assert len(ts) == len(g4[f"state_{name}"])
+        assert np.max(np.abs(ts - g4[f"state_{name}"])) < 1e-12
+        assert np.max(np.abs(tu - g4[f"thrust_{name}"])) < 1e-12
+        assert np.array_equal(tsc, g4[f"score_{name}"]) and np.array_equal(ttg, g4[f"target_{name}"])
+    # BASELINE config 1: 1 drone, 1000 steps, paramset "11"
+    ts, tu, tsc, ttg, score = oracle.pid_episode(sim, g4["paramsets"][names.index("11")], g4["coins"], 1000)
+    assert [score, int(ttg[-1]), len(ts)] == [int(v) for v in g4["cfg1_final"]]
+
+
+def test_open_loop_rungs(oracle, g4):
+    """Short-horizon open-loop on a stable (PID) thrust sequence: what fp32 can promise."""
+    sim = SimParams.reference()
+    U, S = g4["thrust_11"], g4["state_11"]
+    useq = np.vstack([np.zeros((1, 4)), U[:-1]])          # thrust computed at step t acts at t+1
+    tr = oracle.open_loop(sim, useq)
+    assert np.max(np.abs(tr - S)) < 1e-12                  # faithful mode: the reference trajectory
+    tr32 = oracle.open_loop(sim, useq, mode=oracle.CLOSED_F32)
+    span = np.ptp(S[:500, :3])
+    assert np.max(np.abs(tr32[:500, :3] - S[:500, :3])) < 1e-4 * span
+    assert np.max(np.abs(tr32[:500, 6:9] - S[:500, 6:9])) < 1e-4
+
+
+def test_population_threads_match_serial(oracle):
+    sim, ep = SimParams.reference(), EpisodeParams.reference()
+    spec = MlpSpec.from_hidden((16, 16))
+    rng = np.random.default_rng(5)
+    genes = rng.normal(0, 0.3, (64, spec.param_count))
+    a = oracle.fly(sim, ep, spec, genes, 300, n_threads=1)
+    b = oracle.fly(sim, ep, spec, genes, 300, n_threads=4)
+    assert np.array_equal(a.reward, b.reward) and np.array_equal(a.state, b.state)

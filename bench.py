@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py — drone-steps/s of the fused fly() rollout on MI355X (BASELINE.json's metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE config 3, the one the metric is quoted on): 65 536 drones per GPU x 2 000
+timesteps, 15-32-32-4 controller, 3-coin chain, crash penalty on, float32.  A "step" is one whole
+episode of the population = 2 000 launches of the fused step kernel + the finalize launch (+ the
+RCCL all-gather of the 16-byte fitness records when N > 1).  Population shards are independent, so
+scaling is weak: every rank owns 65 536 drones.  Genomes are synthetic: hover controllers
+(learning-drones_amd/controllers.py) with small per-drone noise, so that nearly every drone is
+alive for all 2 000 steps and every counted drone-step does the full work (frozen wavefronts skip
+their gene traffic; the JSON line reports the live fraction).
+
+Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events on the launch stream,
+`cpu_baseline` times the CPU oracle (the stand-in for the reference's Python loop) on the host
+cores, rank 0, N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+WORKLOAD = dict(drones_per_gpu=65536, timesteps=2000, hidden=(32, 32), n_coins=3)
+
+
+def make_genomes(torch, n, hidden, device, seed):
+    from learning_drones_amd import controllers
+    poles = (1.2, 1.6, 2.0, 2.5)
+    bases = np.stack([np.concatenate([w.ravel() for w in controllers.hover_net(hidden, gains=controllers.hover_gains(pole_xy=p))])
+                      for p in poles])
+    g = torch.Generator(device=device)
+    g.manual_seed(0x1D20 + seed)
+    base = torch.as_tensor(bases, dtype=torch.float32, device=device)[torch.arange(n, device=device) % len(poles)]
+    return base + 2e-4 * torch.randn(base.shape, generator=g, device=device, dtype=torch.float32)
+
+
+def cpu_baseline(hidden, n_coins, timesteps):
+    """The oracle (CPU restatement of the reference loop, float64 with the reference's rounding
+    points) on all host cores, on a bounded sample of the same workload."""
+    from learning_drones_amd import controllers
+    from learning_drones_amd.params import EpisodeParams, MlpSpec, SimParams, coin_chain_reference
+    from oracle import oracle as O
+    O.build()
+    cores = O.max_threads()
+    spec = MlpSpec.from_hidden(hidden)
+    base = np.concatenate([w.ravel() for w in controllers.hover_net(hidden)])
+    rng = np.random.default_rng(0)
+    sim, ep, coins = SimParams.reference(), EpisodeParams.reference(n_coins=n_coins), coin_chain_reference(n_coins)
+    probe = base[None, :] + rng.normal(0, 2e-4, (64 * cores, spec.param_count))
+    t0 = time.perf_counter()
+    O.fly(sim, ep, spec, probe, 200, coins=coins, n_threads=cores)
+    rate = len(probe) * 200 / (time.perf_counter() - t0)
+    n = int(min(65536, max(256, rate * 12.0 / timesteps)))           # ~12 s of wall time
+    genes = base[None, :] + rng.normal(0, 2e-4, (n, spec.param_count))
+    t0 = time.perf_counter()
+    O.fly(sim, ep, spec, genes, timesteps, coins=coins, n_threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": n * timesteps / dt, "unit": "drone-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} drones x {timesteps} steps, same controller/coins, float64 oracle, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--drones", type=int, default=WORKLOAD["drones_per_gpu"], help="drones per GPU")
+    ap.add_argument("--timesteps", type=int, default=WORKLOAD["timesteps"])
+    ap.add_argument("--hidden", type=str, default=",".join(map(str, WORKLOAD["hidden"])))
+    ap.add_argument("--coins", type=int, default=WORKLOAD["n_coins"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from learning_drones_amd.parallel import ShardedPopulation
+    from learning_drones_amd.params import coin_chain_reference
+    hidden = tuple(int(h) for h in args.hidden.split(","))
+    n_local, T = args.drones, args.timesteps
+    pop = ShardedPopulation(n_local * world, hidden, coins=coin_chain_reference(args.coins), precision="f32",
+                            device=device, process_group=dist.group.WORLD if dist else None)
+    assert pop.local.n == n_local
+    pop.local.set_genomes(make_genomes(torch, n_local, hidden, device, seed=rank))
+
+    def episode():
+        pop.local.reset()
+        return pop.fly(T)                      # T step launches + finalize (+ all-gather of records)
+
+    def fence():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        episode()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        records = episode()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # live fraction: flight_time / T over the whole population (records are gathered on every rank)
+    flight = records[:, 1].double()
+    live = float(flight.sum().item()) / (records.shape[0] * T)
+
+    # Roofline of the dominant kernel (fly_step_kernel): HIP events on the launch stream around a
+    # run of consecutive step launches -> average launch duration (inter-launch gaps included).
+    roof_launches = 400
+    pop.local.reset()
+    for _ in range(20):
+        pop.local.step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(roof_launches):
+        pop.local.step()
+    e1.record()
+    torch.cuda.synchronize()
+    launch_ms = e0.elapsed_time(e1) / roof_launches
+    bytes_per_launch = pop.local.bytes_per_drone_step * n_local
+    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        n_total = n_local * world
+        value = n_total * T * args.steps / dt
+        out = {
+            "metric": "drone-steps/sec (whole node), 65 536-drone population per GPU",
+            "value": value, "unit": "drone-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 3: {n_local} drones/GPU x {T} timesteps, 15-{'-'.join(map(str, hidden))}-4 "
+                                   f"controller per drone, {args.coins}-coin chain, crash penalty; step = one episode "
+                                   f"({T} fused-step launches + finalize" + (" + RCCL all-gather of fitness records)" if world > 1 else ")"),
+                       "population": n_total, "timesteps": T, "hidden": list(hidden), "coins": args.coins,
+                       "parallelism": f"population sharded x{world}, no data-path collective inside the rollout"},
+            "generations_per_s": args.steps / dt,
+            "live_drone_step_fraction": live,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "fly_step_kernel<float, UnrolledNet<32,32>>" if hidden == (32, 32) else "fly_step_kernel",
+                         "bytes_per_launch": bytes_per_launch, "launch_us": launch_ms * 1e3,
+                         "bytes_per_drone_step": pop.local.bytes_per_drone_step},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(hidden, args.coins, T)
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,7 +82,7 @@ typedef enum ld_ffield {
 typedef enum ld_ifield {
     LD_I_REWARD = 0,
     LD_I_COINS = 1,
-    LD_I_STATUS = 2,            /* +flight_time while flying, -flight_time once crashed */
+    LD_I_STATUS = 2,            /* 2 * flight_time + crashed */
     LD_I_COUNT = 3
 } ld_ifield;
 

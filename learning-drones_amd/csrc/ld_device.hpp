@@ -1,0 +1,232 @@
+// ld_device.hpp — device-side arithmetic of the fused drone step (gfx950 / CDNA4 only).
+//
+// One wavefront lane owns one drone.  Everything here is per-lane scalar code on values held
+// in VGPRs; the only memory traffic is in ld_kernels.hip.  Compile with -ffp-contract=off: the
+// places where a fused multiply-add is wanted say so with fma(), so that the float32 kernel
+// is the same arithmetic as the oracle's CLOSED_F32 mode and the float64 kernel can reproduce
+// the reference's rounding points.
+//
+// Reference (all paths relative to mbecker12/learning-drones):
+//   accelerations   drone/quadcopter/physical_model.py:75-122, drone/quadcopter/geometry.py:15-71
+//   integrator      drone/sensor/sensor.py:42-49, 62-73, 85-93, 128-149
+//   measure         drone/drone.py:129-165
+//   controller      evolve/brain.py:26-54
+//   coin / episode  objects/coins.py:17-25, flight/__init__.py:39-99
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ld_drones.h"
+
+namespace ld {
+
+template <typename Real> struct Math;
+template <> struct Math<float> {
+    static __device__ __forceinline__ void sincos(float x, float* s, float* c) { ::sincosf(x, s, c); }
+    static __device__ __forceinline__ float exp(float x) { return ::expf(x); }
+    static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
+    static __device__ __forceinline__ float abs(float x) { return ::fabsf(x); }
+    static __device__ __forceinline__ float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
+};
+template <> struct Math<double> {
+    static __device__ __forceinline__ void sincos(double x, double* s, double* c) { *s = ::sin(x); *c = ::cos(x); }
+    static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
+    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    static __device__ __forceinline__ double abs(double x) { return ::fabs(x); }
+    static __device__ __forceinline__ double fma(double a, double b, double c) { return ::fma(a, b, c); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Accelerations, closed form: with Rot = (Rz Ry Rx)^T
+//   a_lin = (Rz Ry Rx)[:,2] * sum(T)/m - [0,0,G/m] + wind * c_w/m
+//   a_rot = Tr(roll, pitch) * (([L,M,N] + M_p) * 1/I)
+// ---------------------------------------------------------------------------------------------
+template <typename Real>
+__device__ __forceinline__ void accel_closed(const ld_sim_params& p, const Real ang[3], const Real u[4],
+                                             Real lin[3], Real rot[3])
+{
+    Real sr, cr, sp, cp, sy, cy;
+    Math<Real>::sincos(ang[0], &sr, &cr);
+    Math<Real>::sincos(ang[1], &sp, &cp);
+    Math<Real>::sincos(ang[2], &sy, &cy);
+    const Real cf = (Real)p.coef_force, cm = (Real)p.coef_moment, r = (Real)p.radius_motor;
+    const Real inv_m = (Real)1 / (Real)p.mass_total;
+    const Real T0 = u[0] * cf, T1 = u[1] * cf, T2 = u[2] * cf, T3 = u[3] * cf;
+    const Real R0 = u[0] * cm, R1 = u[1] * cm, R2 = u[2] * cm, R3 = u[3] * cm;
+    const Real thrust_acc = (((T0 + T1) + T2) + T3) * inv_m;
+    const Real cw_m = (Real)p.coef_wind * inv_m;
+    lin[0] = (cy * sp * cr + sy * sr) * thrust_acc + (Real)p.wind[0] * cw_m;
+    lin[1] = (sy * sp * cr - cy * sr) * thrust_acc + (Real)p.wind[1] * cw_m;
+    lin[2] = (cp * cr) * thrust_acc - (Real)p.gravity_force * inv_m + (Real)p.wind[2] * cw_m;
+    const Real L = r * (((T0 + T3) - T1) - T2);
+    const Real M = r * (((T2 + T3) - T0) - T1);
+    const Real N = ((Real)1.4142135623730951 * r) * (((R1 + R3) - R0) - R2);
+    const Real b0 = (L + (Real)p.moments_payload[0]) * (Real)p.inv_inertia[0];
+    const Real b1 = (M + (Real)p.moments_payload[1]) * (Real)p.inv_inertia[1];
+    const Real b2 = (N + (Real)p.moments_payload[2]) * (Real)p.inv_inertia[2];
+    const Real inv_cp = (Real)1 / cp;
+    const Real tp = sp * inv_cp;
+    rot[0] = b0 + (sr * tp) * b1 + (cr * tp) * b2;
+    rot[1] = cr * b1 - sr * b2;
+    rot[2] = (sr * b1 + cr * b2) * inv_cp;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Accelerations, float64 with the reference's float32 rounding points (1)-(4) and the explicit
+// 3x3 products.  The 3-term sums use the summation orders of the BLAS calls that numpy makes
+// for them (pinned by the oracle's golden vectors, oracle/ld_oracle.c):
+//   dgemm / Fortran-ordered dgemv   fma(a2,b2, fma(a1,b1, a0*b0))
+//   C-ordered dgemv                 fma(a2,b2, fma(a0,b0, a1*b1))
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double dot3_gemm(double a0, double b0, double a1, double b1, double a2, double b2)
+{
+    return ::fma(a2, b2, ::fma(a1, b1, a0 * b0));
+}
+__device__ __forceinline__ double dot3_gemv_c(double a0, double b0, double a1, double b1, double a2, double b2)
+{
+    return ::fma(a2, b2, ::fma(a0, b0, a1 * b1));
+}
+
+__device__ __forceinline__ void accel_faithful(const ld_sim_params& p, const double ang[3], const double u[4],
+                                               double lin[3], double rot[3])
+{
+    const double roll = ang[0], pitch = ang[1], yaw = ang[2];
+    const double cr = ::cos(roll), sr = ::sin(roll), cp = ::cos(pitch), sp = ::sin(pitch);
+    const double cy = ::cos(yaw), sy = ::sin(yaw);
+    // geometry.py:23-43  B = Rz (Ry Rx); Rot = B^T
+    const double Rx[3][3] = {{1, 0, 0}, {0, cr, -sr}, {0, sr, cr}};
+    const double Ry[3][3] = {{cp, 0, sp}, {0, 1, 0}, {-sp, 0, cp}};
+    const double Rz[3][3] = {{cy, -sy, 0}, {sy, cy, 0}, {0, 0, 1}};
+    double YX[3][3], B[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            YX[i][j] = dot3_gemm(Ry[i][0], Rx[0][j], Ry[i][1], Rx[1][j], Ry[i][2], Rx[2][j]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            B[i][j] = dot3_gemm(Rz[i][0], YX[0][j], Rz[i][1], YX[1][j], Rz[i][2], YX[2][j]);
+
+    double T[4], R[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { T[i] = u[i] * p.coef_force; R[i] = u[i] * p.coef_moment; }
+    const double sumT = ((T[0] + T[1]) + T[2]) + T[3];
+    float F[3] = {0.0f, 0.0f, (float)sumT};                               // (2) physical_model.py:98
+    const float G32 = (float)(-1 * p.gravity_force);                      // (3) :101
+    float w32[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) w32[i] = (float)p.wind[i] * (float)p.coef_wind;          // :103
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {                                         // Rot[i][k] = B[k][i]
+        const double g = dot3_gemm(B[0][i], 0.0, B[1][i], 0.0, B[2][i], (double)G32);
+        const double w = dot3_gemm(B[0][i], (double)w32[0], B[1][i], (double)w32[1], B[2][i], (double)w32[2]);
+        F[i] = (float)((double)F[i] + (g + w));                           // (2) :104 in-place +=
+    }
+    const double L = p.radius_motor * (((T[0] + T[3]) - T[1]) - T[2]);    // :107-109
+    const double M = p.radius_motor * (((T[2] + T[3]) - T[0]) - T[1]);
+    const double N = (::sqrt(2.0) * p.radius_motor) * (((R[1] + R[3]) - R[0]) - R[2]);
+    const double mom[3] = {L + p.moments_payload[0], M + p.moments_payload[1], N + p.moments_payload[2]};
+    const float m32 = (float)p.mass_total;
+    const float a32[3] = {F[0] / m32, F[1] / m32, F[2] / m32};             // (4) :114 stays float32
+    const double b[3] = {mom[0] * p.inv_inertia[0], mom[1] * p.inv_inertia[1], mom[2] * p.inv_inertia[2]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)                                           // :118  Rot^T . lin_acc
+        lin[i] = dot3_gemv_c(B[i][0], (double)a32[0], B[i][1], (double)a32[1], B[i][2], (double)a32[2]);
+    const double tp = ::tan(pitch);                                       // geometry.py:62-69, (1)
+    const float Tr[3][3] = {{1.0f, (float)(sr * tp), (float)(cr * tp)},
+                            {0.0f, (float)cr, (float)(-sr)},
+                            {0.0f, (float)(sr / cp), (float)(cr / cp)}};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)                                           // :119-120
+        rot[i] = dot3_gemv_c((double)Tr[i][0], b[0], (double)Tr[i][1], b[1], (double)Tr[i][2], b[2]);
+}
+
+template <typename Real, bool Faithful>
+__device__ __forceinline__ void accelerations(const ld_sim_params& p, const Real ang[3], const Real u[4],
+                                              Real lin[3], Real rot[3])
+{
+    if constexpr (Faithful) {
+        static_assert(sizeof(Real) == 8, "the faithful path is float64");
+        accel_faithful(p, ang, u, lin, rot);
+    } else {
+        accel_closed<Real>(p, ang, u, lin, rot);
+    }
+}
+
+// sensor.py:42-49 + :62-73,:85-93 for one coordinate.
+template <typename Real>
+__device__ __forceinline__ void verlet(Real& q, Real& qd, Real& a_cur, Real a, Real dt)
+{
+    const Real a_last = a_cur;
+    a_cur = a;
+    q = q + (qd * dt + (Real)0.5 * a * dt * dt);
+    qd = qd + (Real)0.5 * (a_last + a) * dt;
+}
+
+// Per-lane drone state: 12 integrator coordinates, 6 last accelerations, 4 thrusts.
+template <typename Real> struct DroneRegs {
+    Real s[12];
+    Real acc[6];
+    Real u[4];
+};
+
+// drone/drone.py:129-165 (+ build-defined wall boxes held in LDS).  Returns true if crashed;
+// `reward` receives the crash / instability terms.
+template <typename Real, bool Faithful>
+__device__ __forceinline__ bool measure(const ld_sim_params& sim, const ld_episode_params& ep,
+                                        const Real* __restrict__ lds_walls, DroneRegs<Real>& d, int32_t& reward)
+{
+    Real lin[3], rot[3];
+    const Real dt = (Real)sim.dt;
+    accelerations<Real, Faithful>(sim, &d.s[6], d.u, lin, rot);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) verlet<Real>(d.s[i], d.s[3 + i], d.acc[i], lin[i], dt);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) verlet<Real>(d.s[6 + i], d.s[9 + i], d.acc[3 + i], rot[i], dt);
+    bool hit = (d.s[2] <= (Real)ep.z_floor) || (d.s[2] > (Real)ep.z_ceiling);
+    for (int w = 0; w < ep.n_walls; ++w) {
+        const Real* b = lds_walls + w * LD_WALL_STRIDE;
+        hit = hit || (d.s[0] >= b[0] && d.s[1] >= b[1] && d.s[2] >= b[2] &&
+                      d.s[0] <= b[3] && d.s[1] <= b[4] && d.s[2] <= b[5]);
+    }
+    if (hit) {
+        reward += ep.reward_crashed;
+        return true;
+    }
+    if (Math<Real>::abs(d.s[6]) > (Real)ep.angle_limit) reward += ep.reward_unstable;
+    if (Math<Real>::abs(d.s[7]) > (Real)ep.angle_limit) reward += ep.reward_unstable;
+    if (Math<Real>::abs(d.s[11]) > (Real)ep.angle_vel_limit) reward += ep.reward_unstable;
+    return false;
+}
+
+template <typename Real>
+__device__ __forceinline__ Real coin_distance(const Real* __restrict__ coin, const Real s[12])
+{
+    const Real dx = coin[0] - s[0], dy = coin[1] - s[1], dz = coin[2] - s[2];
+    return Math<Real>::sqrt((dx * dx + dy * dy) + dz * dz);               // objects/coins.py:17-25
+}
+
+// Activation functions of evolve/brain.py:26-39.
+template <typename Real> __device__ __forceinline__ Real relu(Real v) { return (v < (Real)0) ? (Real)0 : v; }
+template <typename Real> __device__ __forceinline__ Real sigmoid04(Real v)
+{
+    return (Real)1 / (Math<Real>::exp((Real)-0.4 * v) + (Real)1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Genome words.  A drone's genes are stored as 16-byte (float) / 32-byte (double) words of four
+// consecutive genes; word w of drone i sits at genomes[w * n + i], so a wavefront's load of one
+// word index is one contiguous 1 KiB (float) line.
+// ---------------------------------------------------------------------------------------------
+template <typename Real> struct alignas(4 * sizeof(Real)) GeneWord { Real g[4]; };
+
+template <typename Real>
+__device__ __forceinline__ GeneWord<Real> load_word(const GeneWord<Real>* __restrict__ lane_base, int64_t n, int w)
+{
+    return lane_base[(int64_t)w * n];
+}
+
+}  // namespace ld

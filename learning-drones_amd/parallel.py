@@ -1,0 +1,91 @@
+"""Population sharding across the GPUs of one node: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+Drones are independent within a generation (the reference evaluates them one after another,
+evolve/evolution.py:64-73), so rank r owns the contiguous drone range shard_bounds(N, W, r) — state
+and genomes of that range live only on GPU r — and the T-step rollout needs no communication.  The
+only exchange is ONE all-gather per generation of the 16-byte per-drone result records
+(ld_fitness_record: reward, flight_time, coins|crashed, distance), after which every rank holds all
+N fitness values and can run the identical seeded selection.  At 65 536 drones per GPU a rank
+contributes 1 MiB; on the fully connected xGMI mesh that is latency-bound (~tens of microseconds)
+against a ~0.2 s rollout, so nothing is bucketed or overlapped.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+
+
+def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
+    """[begin, end) of rank's drones: contiguous, sizes differ by at most one."""
+    if not 0 <= rank < world:
+        raise ValueError("rank out of range")
+    base, rem = divmod(n_total, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def shard_counts(n_total: int, world: int):
+    return [shard_bounds(n_total, world, r)[1] - shard_bounds(n_total, world, r)[0] for r in range(world)]
+
+
+def gather_records(local_records, n_total: int, process_group=None):
+    """All-gather the per-drone result records ([n_local, 4] int32) into [n_total, 4] in global drone
+    order on every rank.  Works on any device/backend pair torch.distributed supports."""
+    import torch
+    import torch.distributed as dist
+    if process_group is None or dist.get_world_size(process_group) == 1:
+        return local_records
+    world = dist.get_world_size(process_group)
+    counts = shard_counts(n_total, world)
+    width = local_records.shape[1]
+    if len(set(counts)) == 1:
+        out = torch.empty((n_total, width), dtype=local_records.dtype, device=local_records.device)
+        dist.all_gather_into_tensor(out, local_records.contiguous(), group=process_group)
+        return out
+    pad = max(counts)
+    buf = torch.zeros((pad, width), dtype=local_records.dtype, device=local_records.device)
+    buf[: local_records.shape[0]] = local_records
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf, group=process_group)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+
+
+class ShardedPopulation:
+    """A population of n_total drones split over the ranks of `process_group`; `local` is this
+    rank's Population shard (learning-drones_amd/population.py)."""
+
+    def __init__(self, n_total: int, hidden, *, process_group=None, device=None, **population_kwargs):
+        from .population import Population
+        self.n_total = int(n_total)
+        self.group = process_group
+        if process_group is None:
+            self.rank, self.world = 0, 1
+        else:
+            import torch.distributed as dist
+            self.rank, self.world = dist.get_rank(process_group), dist.get_world_size(process_group)
+        self.begin, self.end = shard_bounds(self.n_total, self.world, self.rank)
+        self.local = Population(self.end - self.begin, hidden, device=device, **population_kwargs)
+
+    def set_genomes(self, rows_global) -> None:
+        """rows_global: [n_total, P] on every rank (host array or tensor); each rank keeps its slice."""
+        self.local.set_genomes(rows_global[self.begin:self.end])
+
+    def fly(self, timesteps: int):
+        """Rollout of the local shard, then the generation-end all-gather.  Returns the [n_total, 4]
+        int32 record tensor (global drone order) on every rank."""
+        local = self.local.fly(timesteps)
+        return gather_records(local, self.n_total, self.group)
+
+    @staticmethod
+    def records_to_numpy(records) -> np.ndarray:
+        from .params import CRASHED_BIT, FITNESS_DTYPE
+        raw = records.cpu().numpy().view(FITNESS_DTYPE).reshape(-1)
+        out = np.zeros(len(raw), dtype=[("reward", "<i4"), ("flight_time", "<i4"), ("coins", "<i4"),
+                                        ("crashed", "?"), ("distance_to_coin", "<f4")])
+        out["reward"], out["flight_time"] = raw["reward"], raw["flight_time"]
+        out["coins"] = raw["coins_crashed"] & (CRASHED_BIT - 1)
+        out["crashed"] = (raw["coins_crashed"] & CRASHED_BIT) != 0
+        out["distance_to_coin"] = raw["distance_to_coin"]
+        return out

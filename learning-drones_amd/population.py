@@ -1,0 +1,242 @@
+"""Population: the batched analogue of a list of reference ``Drone`` objects.
+
+All per-drone data lives in HBM as struct-of-arrays PyTorch-ROCm tensors (PyTorch is used for
+device memory and streams only); every computation is a call through the C ABI of
+include/ld_drones.h into the hand-written HIP kernels.  There is no CPU path.
+
+Reference objects this replaces, for n drones at once:
+  Drone state + reward bookkeeping   drone/drone.py:21-76, 129-165, 177-218
+  NeuralNetwork weights              evolve/brain.py:10-24 (per-drone genome)
+  fly()                              flight/__init__.py:12-99
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+
+from . import _native
+from .params import (COIN_STRIDE, CRASHED_BIT, F_ACC, F_ANGLE, F_ANGVEL, F_COUNT, F_POS, F_THRUST, F_VEL,
+                     FITNESS_DTYPE, I_COINS, I_COUNT, I_REWARD, I_STATUS, INITIAL_STATE, MAX_COINS, WALL_STRIDE,
+                     EpisodeParams, MlpSpec, SimParams, coin_chain_reference, flatten_weights, unflatten_weights)
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class Population:
+    """n drones with one controller genome each, resident on one GPU.
+
+    precision: "f32" (production kernels) or "f64" (reference-tracking kernels that reproduce the
+    reference's float32 rounding points; validation mode, 2x the bytes).
+    """
+
+    def __init__(self, n: int, hidden: Iterable[int] = (10, 10), *, precision: str = "f32",
+                 device: Optional[str] = None, sim: Optional[SimParams] = None,
+                 episode: Optional[EpisodeParams] = None, coins: Optional[np.ndarray] = None,
+                 walls: Optional[np.ndarray] = None, init_state: Optional[Sequence[float]] = None):
+        torch = _torch()
+        _native.require_gpu()
+        if precision not in ("f32", "f64"):
+            raise ValueError("precision must be 'f32' or 'f64'")
+        self.n = int(n)
+        if self.n < 0:
+            raise ValueError("n must be >= 0")
+        self.spec = hidden if isinstance(hidden, MlpSpec) else MlpSpec.from_hidden(hidden)
+        self.precision = precision
+        self.dtype = torch.float32 if precision == "f32" else torch.float64
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.sim = sim if sim is not None else SimParams.reference()
+        coins = coin_chain_reference(MAX_COINS) if coins is None else np.ascontiguousarray(coins, np.float64).reshape(-1, COIN_STRIDE)
+        walls = np.zeros((0, WALL_STRIDE)) if walls is None else np.ascontiguousarray(walls, np.float64).reshape(-1, WALL_STRIDE)
+        self.episode = episode if episode is not None else EpisodeParams.reference()
+        self.episode.n_coins, self.episode.n_walls = len(coins), len(walls)
+        self.coins_host, self.walls_host = coins, walls
+        self.init_state = np.asarray(INITIAL_STATE if init_state is None else init_state, np.float64).reshape(12).copy()
+
+        P, W = self.spec.param_count, self.spec.words_per_drone
+        self.P, self.W = P, W
+        dev, n = self.device, self.n
+        self.fstate = torch.zeros((F_COUNT, n), dtype=self.dtype, device=dev)
+        self.istate = torch.zeros((I_COUNT, n), dtype=torch.int32, device=dev)
+        self.genomes = torch.zeros((W, n, 4), dtype=self.dtype, device=dev)
+        self.records = torch.zeros((n, 4), dtype=torch.int32, device=dev)          # ld_fitness_record[n]
+        self.distance = torch.zeros((n,), dtype=torch.float64, device=dev) if precision == "f64" else None
+        self.coins_dev = torch.from_numpy(coins).to(dev)
+        self.walls_dev = torch.from_numpy(walls).to(dev) if len(walls) else None
+        self._finalized = False
+        self.reset()
+
+    # ------------------------------------------------------------------ plumbing
+    def _fn(self, name: str):
+        return getattr(_native.lib(), f"{name}_{self.precision}")
+
+    def _stream(self) -> C.c_void_p:
+        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _ptr(t) -> C.c_void_p:
+        return C.c_void_p(0 if t is None or t.numel() == 0 else t.data_ptr())
+
+    # ------------------------------------------------------------------ genomes
+    def set_genomes(self, rows) -> None:
+        """rows: [n, P] gene vectors in reference order (numpy or torch, any float dtype)."""
+        torch = _torch()
+        rows = torch.as_tensor(rows)
+        if tuple(rows.shape) != (self.n, self.P):
+            raise ValueError(f"expected genes of shape ({self.n}, {self.P}), got {tuple(rows.shape)}")
+        rows = rows.to(device=self.device, dtype=self.dtype).contiguous()
+        if self.n:
+            _native.check(self._fn("ld_genomes_pack")(self._ptr(rows), self.P, self._ptr(self.genomes), self.n, self.P,
+                                                      self._stream()), "ld_genomes_pack")
+
+    def get_genomes(self):
+        """[n, P] gene vectors (torch tensor on the device)."""
+        rows = _torch().empty((self.n, self.P), dtype=self.dtype, device=self.device)
+        if self.n:
+            _native.check(self._fn("ld_genomes_unpack")(self._ptr(self.genomes), self._ptr(rows), self.P, self.n, self.P,
+                                                        self._stream()), "ld_genomes_unpack")
+        return rows
+
+    def set_controllers(self, controllers: Sequence) -> None:
+        """controllers: n objects with ``.weights`` (reference NeuralNetwork format) or n weights lists."""
+        if len(controllers) != self.n:
+            raise ValueError(f"expected {self.n} controllers")
+        rows = np.stack([flatten_weights(getattr(c, "weights", c)) for c in controllers]) if self.n else np.zeros((0, self.P))
+        self.set_genomes(rows)
+
+    def get_controllers(self) -> list:
+        rows = self.get_genomes().double().cpu().numpy()
+        return [unflatten_weights(r, self.spec) for r in rows]
+
+    def init_genomes_reference(self, seed: int) -> None:
+        """Genomes ~ N(0, 1/sqrt(n_neurons)) per layer, bias included (evolve/brain.py:24), drawn on
+        the device with a Philox stream (statistically, not bitwise, the reference's MT19937 draw)."""
+        torch = _torch()
+        g = torch.Generator(device=self.device)
+        g.manual_seed(int(seed))
+        cols = []
+        for n_out, n_in1 in self.spec.layer_shapes:
+            cols.append(torch.randn((self.n, n_out * n_in1), generator=g, device=self.device, dtype=torch.float32)
+                        / float(np.sqrt(n_out)))
+        self.set_genomes(torch.cat(cols, dim=1) if self.n else torch.zeros((0, self.P)))
+
+    # ------------------------------------------------------------------ state
+    def reset(self, init_state: Optional[Sequence[float]] = None) -> None:
+        """Drone.reset() for every drone (drone/drone.py:177-218)."""
+        if init_state is not None:
+            self.init_state = np.asarray(init_state, np.float64).reshape(12).copy()
+        init = self.init_state.ctypes.data_as(C.POINTER(C.c_double))
+        _native.check(self._fn("ld_population_reset")(self._ptr(self.fstate), self._ptr(self.istate), self.n, init,
+                                                      self._stream()), "ld_population_reset")
+        self._finalized = False
+
+    def set_state(self, state12=None, acc6=None, thrust4=None) -> None:
+        """Overwrite per-drone state from [n, k] arrays (used by tests and by the scalar Drone)."""
+        torch = _torch()
+        for arr, off, k in ((state12, F_POS, 12), (acc6, F_ACC, 6), (thrust4, F_THRUST, 4)):
+            if arr is not None:
+                t = torch.as_tensor(np.asarray(arr, np.float64).reshape(self.n, k)).to(self.device, self.dtype)
+                self.fstate[off:off + k] = t.t()
+
+    @property
+    def position(self): return self.fstate[F_POS:F_POS + 3]
+    @property
+    def velocity(self): return self.fstate[F_VEL:F_VEL + 3]
+    @property
+    def angle(self): return self.fstate[F_ANGLE:F_ANGLE + 3]
+    @property
+    def angle_vel(self): return self.fstate[F_ANGVEL:F_ANGVEL + 3]
+    @property
+    def acceleration(self): return self.fstate[F_ACC:F_ACC + 6]
+    @property
+    def thrust(self): return self.fstate[F_THRUST:F_THRUST + 4]
+    @property
+    def reward(self): return self.istate[I_REWARD]
+    @property
+    def coins(self): return self.istate[I_COINS]
+    @property
+    def flight_time(self): return self.istate[I_STATUS] >> 1
+    @property
+    def crashed(self): return (self.istate[I_STATUS] & 1).bool()
+
+    def state_numpy(self) -> np.ndarray:
+        """[n, 22] float64: pos3 vel3 angle3 angle_vel3 acc6 thrust4."""
+        return self.fstate.t().double().cpu().numpy()
+
+    # ------------------------------------------------------------------ kernels
+    def measure(self) -> None:
+        """Drone.measure for all live drones (drone/drone.py:129-165)."""
+        _native.check(self._fn("ld_measure")(C.byref(self.sim), C.byref(self.episode), self._ptr(self.fstate),
+                                             self._ptr(self.istate), self.n, self._stream()), "ld_measure")
+
+    def feed_forward(self, inputs):
+        """NeuralNetwork.feed_forward for every genome: inputs [15, n] -> thrust [4, n]."""
+        torch = _torch()
+        x = torch.as_tensor(inputs).to(self.device, self.dtype).contiguous()
+        if tuple(x.shape) != (15, self.n):
+            raise ValueError(f"inputs must be (15, {self.n})")
+        y = torch.empty((4, self.n), dtype=self.dtype, device=self.device)
+        _native.check(self._fn("ld_mlp_forward")(C.byref(self.spec), self._ptr(self.genomes), self._ptr(x), self._ptr(y),
+                                                 self.n, self._stream()), "ld_mlp_forward")
+        return y
+
+    def step(self) -> None:
+        """One iteration of fly()'s loop for the whole population = ONE kernel launch."""
+        _native.check(self._fn("ld_fly_step")(C.byref(self.sim), C.byref(self.episode), C.byref(self.spec),
+                                              self._ptr(self.coins_dev), self._ptr(self.walls_dev),
+                                              self._ptr(self.genomes), self._ptr(self.fstate), self._ptr(self.istate),
+                                              self.n, self._stream()), "ld_fly_step")
+
+    def finalize(self) -> None:
+        """Tail of fly(): distance penalty + result records (flight/__init__.py:83-87,97-99)."""
+        if self._finalized:
+            raise RuntimeError("finalize() already applied the distance penalty for this episode; reset() first")
+        if self.precision == "f32":
+            rc = self._fn("ld_fly_finalize")(C.byref(self.episode), self._ptr(self.coins_dev), self._ptr(self.fstate),
+                                             self._ptr(self.istate), self._ptr(self.records), self.n, self._stream())
+        else:
+            rc = self._fn("ld_fly_finalize")(C.byref(self.episode), self._ptr(self.coins_dev), self._ptr(self.fstate),
+                                             self._ptr(self.istate), self._ptr(self.records), self._ptr(self.distance),
+                                             self.n, self._stream())
+        _native.check(rc, "ld_fly_finalize")
+        self._finalized = True
+
+    def fly(self, timesteps: int = 2500):
+        """fly(drone, timesteps) for every drone: `timesteps` fused-step launches + finalize, enqueued
+        from C on the current stream.  Returns the device tensor of result records ([n, 4] int32
+        view of ld_fitness_record); see results()."""
+        if self._finalized:
+            raise RuntimeError("episode already finalized; reset() first")
+        args = [C.byref(self.sim), C.byref(self.episode), C.byref(self.spec), self._ptr(self.coins_dev),
+                self._ptr(self.walls_dev), self._ptr(self.genomes), self._ptr(self.fstate), self._ptr(self.istate),
+                self._ptr(self.records)]
+        if self.precision == "f64":
+            args.append(self._ptr(self.distance))
+        args += [self.n, int(timesteps), self._stream()]
+        _native.check(self._fn("ld_fly_rollout")(*args), "ld_fly_rollout")
+        self._finalized = True
+        return self.records
+
+    def results(self) -> np.ndarray:
+        """Host copy of the result records as a structured array with the extra convenience fields
+        of fly()/Drone: reward, flight_time, coins, crashed, distance_to_coin."""
+        raw = self.records.cpu().numpy().view(FITNESS_DTYPE).reshape(self.n)
+        out = np.zeros(self.n, dtype=[("reward", "<i4"), ("flight_time", "<i4"), ("coins", "<i4"),
+                                      ("crashed", "?"), ("distance_to_coin", "<f8")])
+        out["reward"], out["flight_time"] = raw["reward"], raw["flight_time"]
+        out["coins"] = raw["coins_crashed"] & (CRASHED_BIT - 1)
+        out["crashed"] = (raw["coins_crashed"] & CRASHED_BIT) != 0
+        out["distance_to_coin"] = raw["distance_to_coin"] if self.distance is None else self.distance.cpu().numpy()
+        return out
+
+    # ------------------------------------------------------------------ accounting
+    @property
+    def bytes_per_drone_step(self) -> int:
+        """Algorithmic HBM bytes of one fused drone-step: genes once + 25 state words read and
+        written (4P + 200 for float32)."""
+        word = 4 if self.precision == "f32" else 8
+        return word * (self.P + 2 * F_COUNT) + 4 * 2 * I_COUNT

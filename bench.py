@@ -149,6 +149,16 @@ def main():
     bytes_per_launch = pop.local.bytes_per_drone_step * n_local
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
 
+    # HBM bytes per launch from the PMC counters: collected by separate rocprofv3 --pmc passes of this
+    # same command and committed under profiles/ (they cannot be read live); used only when the
+    # profiled launch configuration is the one being run.
+    traffic, traffic_src = None, None
+    for f in sorted((REPO / "profiles").glob("r*_fly_step_pmc.json"), reverse=True):
+        prof = json.loads(f.read_text())
+        if prof["config"]["drones"] == n_local and tuple(prof["config"]["hidden"]) == hidden and prof["config"]["coins"] == args.coins:
+            traffic, traffic_src = prof["hbm_traffic_bytes_per_launch"], f"profiles/{f.name}"
+            break
+
     if rank == 0:
         n_total = n_local * world
         value = n_total * T * args.steps / dt
@@ -165,7 +175,7 @@ def main():
             "generations_per_s": args.steps / dt,
             "live_drone_step_fraction": live,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "fly_step_kernel<float, UnrolledNet<32,32>>" if hidden == (32, 32) else "fly_step_kernel",
                          "bytes_per_launch": bytes_per_launch, "launch_us": launch_ms * 1e3,
                          "bytes_per_drone_step": pop.local.bytes_per_drone_step},

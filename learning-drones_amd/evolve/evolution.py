@@ -1,0 +1,78 @@
+"""The GA driver: evolve/evolution.py:33-119 as a callable.  Same loop shape (evaluate -> argmax ->
+keep global best -> selection_and_crossover -> reset + mutate -> elitism in slot 0) and the same
+hyper-parameter names (evolution.py:16-20); the per-drone `fly(drone, idx=i)` calls become ONE
+batched rollout per generation (flight.fly_population)."""
+from __future__ import annotations
+
+import json
+from copy import deepcopy
+from time import time
+from typing import Callable, Optional
+
+import numpy as np
+
+from ..drone.drone import Drone
+from ..flight import fly_population
+from ..params import flatten_weights
+from .util import selection_and_crossover
+
+n_generations = 20
+n_drones = 20
+mutation_rate = 0.05
+p_tournament = 0.6
+p_crossover = 0.05
+
+
+def save_drone(drone: Drone, path: str, **extra) -> None:
+    """Checkpoint of one drone as plain JSON (the reference writes jsonpickle, evolution.py:85-87;
+    jsonpickle is not a dependency here)."""
+    doc = {"layer_spec": {str(k): int(v) for k, v in drone.controller.layer_spec.items() if k != 0},
+           "genes": flatten_weights(drone.controller.weights).tolist(), "reward": int(drone.reward),
+           "coins": int(drone.coins), "flight_time": int(drone.flight_time), "crashed": bool(drone.crashed),
+           "distance_to_coin": float(drone.distance_to_coin), **extra}
+    with open(path, "w") as f:
+        json.dump(doc, f)
+
+
+def load_drone(path: str, precision: str = "f64") -> Drone:
+    from ..evolve.brain import NeuralNetwork
+    from ..params import unflatten_weights
+    with open(path) as f:
+        doc = json.load(f)
+    d = Drone(visualize=False, n_servers=0, precision=precision)
+    d.controller = NeuralNetwork(layer_spec={int(k): v for k, v in doc["layer_spec"].items()}, precision=precision)
+    d.controller.weights = unflatten_weights(np.asarray(doc["genes"]), d.controller.spec)
+    return d
+
+
+def evolve(n_generations: int = n_generations, n_drones: int = n_drones, mutation_rate: float = mutation_rate,
+           p_tournament: float = p_tournament, p_crossover: float = p_crossover, timesteps: int = 2500,
+           precision: str = "f32", checkpoint: Optional[str] = None, log: Callable = print, drones=None):
+    """Run the GA; returns (global_best_drone, history) where history[g] = (best_score, global_best,
+    scores, times)."""
+    drones = drones if drones is not None else [Drone(visualize=False, n_servers=0, precision=precision)
+                                                for _ in range(n_drones)]
+    global_best_score, global_best_drone, history = -np.inf, None, []
+    for gen in range(n_generations):
+        t0 = time()
+        scores, times = fly_population(drones, timesteps=timesteps, precision=precision)
+        best_index = int(np.argmax(scores))
+        best_score = scores[best_index]
+        if best_score > global_best_score:
+            global_best_score, global_best_drone = best_score, deepcopy(drones[best_index])
+            if checkpoint:
+                save_drone(global_best_drone, checkpoint, generation=gen)
+        new_population = selection_and_crossover(drones, p_tournament, p_crossover)
+        for drone in new_population:
+            drone.reset()
+            drone.mutate(mutation_rate)
+        log(f"Generation {gen}: Best Score: {best_score}, Global Best: {global_best_score} "
+            f"(coins {global_best_drone.coins}, crashed {global_best_drone.crashed}, "
+            f"time in air {global_best_drone.flight_time}, distance {global_best_drone.distance_to_coin:.2f}) "
+            f"[{time() - t0:.2f} s]")
+        history.append((best_score, global_best_score, list(scores), list(times)))
+        drones = new_population
+        elite = deepcopy(global_best_drone)
+        elite.reset()
+        drones[0] = elite
+    return global_best_drone, history

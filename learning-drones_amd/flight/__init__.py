@@ -1,0 +1,60 @@
+"""fly(): mirror of flight/__init__.py:12-99, plus fly_population() which evaluates a whole list of
+Drones in one batched rollout (what evolve/evolution.py's loop over `fly(drone, idx=i)` becomes)."""
+from __future__ import annotations
+
+from typing import Sequence
+
+import numpy as np
+
+from ..params import EpisodeParams, SimParams, coin_chain_reference
+
+
+def _check_episode_args(delta_t, visualize, n_servers):
+    if visualize or n_servers:
+        raise NotImplementedError("visualisation / data-scraper servers are out of scope of learning-drones_amd")
+    if abs(delta_t - 0.01) > 0:
+        # in the reference delta_t only labels the returned time; the integrator step is drone.py:10
+        pass
+
+
+def fly_population(drones: Sequence, timesteps: int = 2500, delta_t: float = 0.01, punish_time=False,
+                   reward_time=True, precision: str | None = None, coins=None, walls=None):
+    """Evaluate every drone of the list with ONE population rollout on the GPU and write the outcome
+    back into the Drone objects (reward, coins, flight_time, crashed, distance_to_coin, position ...).
+    Returns (scores, times): what the reference collects from fly(drone, idx=i) for i in range(n)."""
+    from ..population import Population
+    if not drones:
+        return [], []
+    precision = precision or getattr(drones[0], "precision", "f32")
+    spec = drones[0].controller.spec
+    n = len(drones)
+    coins = coin_chain_reference() if coins is None else coins
+    pop = Population(n, spec.hidden_widths, precision=precision, coins=coins, walls=walls,
+                     episode=EpisodeParams.reference(punish_time=punish_time, reward_time=reward_time),
+                     sim=SimParams.reference())
+    pop.set_genomes(np.stack([d.genes for d in drones]))
+    pop.set_state(np.stack([d._state12() for d in drones]), np.stack([d._acc6() for d in drones]),
+                  np.stack([d.thrust.ravel() for d in drones]))
+    start = np.array([[d.reward, d.coins, 2 * d.flight_time + int(d.crashed)] for d in drones], np.int32)
+    import torch
+    pop.istate.copy_(torch.from_numpy(start.T.copy()))
+    pop.fly(timesteps)
+    res, state = pop.results(), pop.state_numpy()
+    scores, times = [], []
+    for i, d in enumerate(drones):
+        d._store(state[i])
+        d.reward, d.coins, d.flight_time = int(res["reward"][i]), int(res["coins"][i]), int(res["flight_time"][i])
+        d.crashed = bool(res["crashed"][i])
+        d.distance_to_coin = float(res["distance_to_coin"][i])
+        last_step = (d.flight_time - 1) if d.crashed else (timesteps - 1)      # flight/__init__.py:40,87,99
+        scores.append(d.reward)
+        times.append(last_step * delta_t)
+    return scores, times
+
+
+def fly(drone, timesteps: int = 2500, delta_t: float = 0.01, visualize=False, n_servers=0, punish_time=False,
+        reward_time=True, idx=None):
+    """One episode for one Drone.  Returns (reward, real_time, idx) like the reference."""
+    _check_episode_args(delta_t, visualize, n_servers)
+    scores, times = fly_population([drone], timesteps, delta_t, punish_time, reward_time)
+    return scores[0], times[0], idx

@@ -217,6 +217,46 @@ int ld_fly_rollout_f64(const ld_sim_params *sim, const ld_episode_params *ep, co
                        double *fstate, int32_t *istate, ld_fitness_record *records,
                        double *distance_f64, int64_t n, int32_t timesteps, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Generation step on the device: the GA operators of evolve/util.py:5-78 and
+ * Drone.mutate (drone/drone.py:167-172) applied to the device genome layout.  Random numbers come
+ * from Philox4x32-10 keyed by (seed, generation, slot), so the result is a pure function of its
+ * inputs (every rank computes the same parents from the same all-gathered fitness vector) but it is
+ * only STATISTICALLY the reference's numpy MT19937 stream; the host mirrors in
+ * learning-drones_amd/evolve/util.py reproduce that stream bit for bit.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ld_ga_params {
+    double p_tournament;        /* 0.6   evolve/evolution.py:19 */
+    double p_crossover;         /* 0.05  evolve/evolution.py:20, per layer */
+    double mutation_rate;       /* 0.05  evolve/evolution.py:18, per gene */
+    double mutation_sigma;      /* 0.3   drone/drone.py:172 */
+    uint64_t seed;
+    int32_t generation;
+    int32_t reserved;
+} ld_ga_params;
+
+/* selection_and_crossover's draws (evolve/util.py:8-14,30-45,52-56) for the children
+ * [child_begin, child_begin + n_children) of a population of n_total (both even): per pair four
+ * uniform indices and two binary tournaments on fitness[n_total] (device, int32), then per layer a
+ * Bernoulli(p_crossover) cut point.  Writes parents[n_children] (global drone indices) and
+ * cuts[n_children/2][n_hidden+1] (cut index inside the layer, or -1). */
+int ld_ga_select(const ld_ga_params *ga, const ld_mlp_spec *spec, const int32_t *fitness, int64_t n_total,
+                 int64_t child_begin, int64_t n_children, int32_t *parents, int32_t *cuts, void *stream);
+
+/* Builds the children's genomes: copy of the selected parent, single-point crossover with the pair
+ * partner's parent per layer (evolve/util.py:58-68), then per-gene Bernoulli(mutation_rate) *
+ * N(0, mutation_sigma) (drone/drone.py:167-172).  src holds n_segments back-to-back genome arrays of
+ * n_per_segment drones each (the all-gathered shards; 1 segment on a single GPU); global parent g
+ * lives in segment g / n_per_segment, slot g % n_per_segment.  If elite != NULL (device, W words of
+ * one genome) global child 0 becomes an unmutated copy of it (evolve/evolution.py:105-107).
+ * dst is the children's genome array [W][n_children][4]; it must not alias src. */
+int ld_ga_breed_f32(const ld_ga_params *ga, const ld_mlp_spec *spec, const float *src, int64_t n_per_segment,
+                    int32_t n_segments, const int32_t *parents, const int32_t *cuts, const float *elite,
+                    int64_t child_begin, int64_t n_children, float *dst, void *stream);
+int ld_ga_breed_f64(const ld_ga_params *ga, const ld_mlp_spec *spec, const double *src, int64_t n_per_segment,
+                    int32_t n_segments, const int32_t *parents, const int32_t *cuts, const double *elite,
+                    int64_t child_begin, int64_t n_children, double *dst, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

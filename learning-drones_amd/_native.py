@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-from .params import EpisodeParams, FitnessRecord, MlpSpec, SimParams
+from .params import EpisodeParams, FitnessRecord, GaParams, MlpSpec, SimParams
 
 PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "libld_drones.so"
@@ -23,6 +23,7 @@ EXPORTS = (
     "ld_population_reset_f32", "ld_population_reset_f64", "ld_measure_f32", "ld_measure_f64",
     "ld_mlp_forward_f32", "ld_mlp_forward_f64", "ld_fly_step_f32", "ld_fly_step_f64",
     "ld_fly_finalize_f32", "ld_fly_finalize_f64", "ld_fly_rollout_f32", "ld_fly_rollout_f64",
+    "ld_ga_select", "ld_ga_breed_f32", "ld_ga_breed_f64",
 )
 
 
@@ -85,6 +86,10 @@ def _declare(h: C.CDLL) -> None:
     h.ld_fly_finalize_f64.argtypes = [ep, vp, vp, vp, vp, vp, i64, vp]
     h.ld_fly_rollout_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, i64, i32, vp]
     h.ld_fly_rollout_f64.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]
+    ga = C.POINTER(GaParams)
+    h.ld_ga_select.argtypes = [ga, spec, vp, i64, i64, i64, vp, vp, vp]
+    h.ld_ga_breed_f32.argtypes = [ga, spec, vp, i64, i32, vp, vp, vp, i64, i64, vp, vp]
+    h.ld_ga_breed_f64.argtypes = [ga, spec, vp, i64, i32, vp, vp, vp, i64, i64, vp, vp]
     for name in EXPORTS:
         if name not in ("ld_strerror", "ld_last_hip_error", "ld_mlp_param_count", "ld_mlp_words_per_drone"):
             getattr(h, name).restype = C.c_int

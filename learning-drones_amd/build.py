@@ -21,7 +21,7 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB = PKG_DIR / "libld_drones.so"
 SOURCES = [CSRC / "ld_kernels.hip"]
-HEADERS = [CSRC / "ld_device.hpp", CSRC / "ld_nets.hpp", PKG_DIR.parent / "include" / "ld_drones.h"]
+HEADERS = [CSRC / "ld_device.hpp", CSRC / "ld_nets.hpp", CSRC / "ld_ga.hpp", PKG_DIR.parent / "include" / "ld_drones.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
          "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 

@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstring>
 
+#include "ld_ga.hpp"
 #include "ld_nets.hpp"
 
 namespace ld {
@@ -430,9 +431,58 @@ int layout_impl(Real* rows, int64_t row_stride, Real* genomes, int64_t n, int64_
     return check_launch("genome_layout_kernel");
 }
 
+template <typename Real>
+int breed_impl(const ld_ga_params* ga, const ld_mlp_spec* spec, const Real* src, int64_t n_per_segment, int32_t n_segments,
+               const int32_t* parents, const int32_t* cuts, const Real* elite, int64_t child_begin, int64_t n_children,
+               Real* dst, void* stream)
+{
+    if (!ga) return LD_ERR_NULL;
+    const int rc = check_spec(spec);
+    if (rc) return rc;
+    if (n_children < 0 || (n_children & 1) || (child_begin & 1) || child_begin < 0 || n_per_segment < 1 || n_segments < 1)
+        return LD_ERR_SIZE;
+    if (n_children == 0) return LD_OK;
+    if (!src || !parents || !cuts || !dst) return LD_ERR_NULL;
+    if (src == dst) return LD_ERR_SIZE;
+    if (!aligned16(src) || !aligned16(dst) || (elite && !aligned16(elite))) return LD_ERR_ALIGN;
+    const ld::LayerTable lt = ld::layer_table(*spec);
+    const int64_t W = (lt.offset[lt.n_layers] + 3) / 4;
+    hipLaunchKernelGGL((ld::ga_breed_kernel<Real>), dim3(blocks_for(W * n_children, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), *ga, lt, reinterpret_cast<const ld::GeneWord<Real>*>(src),
+                       n_per_segment, parents, cuts, reinterpret_cast<const ld::GeneWord<Real>*>(elite), child_begin,
+                       n_children, reinterpret_cast<ld::GeneWord<Real>*>(dst));
+    return check_launch("ga_breed_kernel");
+}
+
 }  // namespace
 
 extern "C" {
+
+int ld_ga_select(const ld_ga_params* ga, const ld_mlp_spec* spec, const int32_t* fitness, int64_t n_total,
+                 int64_t child_begin, int64_t n_children, int32_t* parents, int32_t* cuts, void* stream)
+{
+    if (!ga) return LD_ERR_NULL;
+    const int rc = check_spec(spec);
+    if (rc) return rc;
+    if (n_total < 2 || n_total > 0x7fffffff || (n_total & 1) || n_children < 0 || (n_children & 1) || child_begin < 0 ||
+        (child_begin & 1) || child_begin + n_children > n_total)
+        return LD_ERR_SIZE;
+    if (n_children == 0) return LD_OK;
+    if (!fitness || !parents || !cuts) return LD_ERR_NULL;
+    hipLaunchKernelGGL(ld::ga_select_kernel, dim3(blocks_for(n_children / 2, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), *ga, ld::layer_table(*spec), fitness, n_total, child_begin,
+                       n_children / 2, parents, cuts);
+    return check_launch("ga_select_kernel");
+}
+
+int ld_ga_breed_f32(const ld_ga_params* ga, const ld_mlp_spec* spec, const float* src, int64_t n_per_segment,
+                    int32_t n_segments, const int32_t* parents, const int32_t* cuts, const float* elite,
+                    int64_t child_begin, int64_t n_children, float* dst, void* stream)
+{ return breed_impl<float>(ga, spec, src, n_per_segment, n_segments, parents, cuts, elite, child_begin, n_children, dst, stream); }
+int ld_ga_breed_f64(const ld_ga_params* ga, const ld_mlp_spec* spec, const double* src, int64_t n_per_segment,
+                    int32_t n_segments, const int32_t* parents, const int32_t* cuts, const double* elite,
+                    int64_t child_begin, int64_t n_children, double* dst, void* stream)
+{ return breed_impl<double>(ga, spec, src, n_per_segment, n_segments, parents, cuts, elite, child_begin, n_children, dst, stream); }
 
 int ld_version(void) { return LD_ABI_VERSION; }
 

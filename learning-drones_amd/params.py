@@ -142,6 +142,18 @@ class MlpSpec(C.Structure):
         return d
 
 
+class GaParams(C.Structure):
+    """struct ld_ga_params; defaults are the hyper-parameters of evolve/evolution.py:16-20 and the
+    mutation width of drone/drone.py:172."""
+    _fields_ = [("p_tournament", C.c_double), ("p_crossover", C.c_double), ("mutation_rate", C.c_double),
+                ("mutation_sigma", C.c_double), ("seed", C.c_uint64), ("generation", C.c_int32), ("reserved", C.c_int32)]
+
+    @classmethod
+    def reference(cls, seed: int = 0, generation: int = 0, p_tournament=0.6, p_crossover=0.05, mutation_rate=0.05,
+                  mutation_sigma=0.3) -> "GaParams":
+        return cls(p_tournament, p_crossover, mutation_rate, mutation_sigma, seed, generation, 0)
+
+
 class FitnessRecord(C.Structure):
     """struct ld_fitness_record (16 bytes)."""
     _fields_ = [("reward", C.c_int32), ("flight_time", C.c_int32), ("coins_crashed", C.c_int32),

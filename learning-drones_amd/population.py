@@ -19,7 +19,8 @@ import numpy as np
 from . import _native
 from .params import (COIN_STRIDE, CRASHED_BIT, F_ACC, F_ANGLE, F_ANGVEL, F_COUNT, F_POS, F_THRUST, F_VEL,
                      FITNESS_DTYPE, I_COINS, I_COUNT, I_REWARD, I_STATUS, INITIAL_STATE, MAX_COINS, WALL_STRIDE,
-                     EpisodeParams, MlpSpec, SimParams, coin_chain_reference, flatten_weights, unflatten_weights)
+                     EpisodeParams, GaParams, MlpSpec, SimParams, coin_chain_reference, flatten_weights,
+                     unflatten_weights)
 
 
 def _torch():
@@ -232,6 +233,43 @@ class Population:
         out["crashed"] = (raw["coins_crashed"] & CRASHED_BIT) != 0
         out["distance_to_coin"] = raw["distance_to_coin"] if self.distance is None else self.distance.cpu().numpy()
         return out
+
+    # ------------------------------------------------------------------ generation step (device GA)
+    def genome_of(self, slot: int):
+        """The W x 4 genome words of one drone (device tensor; the elite buffer of breed())."""
+        return self.genomes[:, slot, :].contiguous()
+
+    def breed(self, fitness_all, ga: GaParams, *, elite=None, child_begin: int = 0, src=None,
+              n_per_segment: Optional[int] = None, n_segments: int = 1) -> None:
+        """Replace this population's genomes by the next generation (evolve/util.py:5-78 +
+        drone/drone.py:167-172 + the elitism of evolve/evolution.py:105-107), on the device.
+
+        fitness_all: int32 device tensor with the fitness of ALL n_total drones (this shard's
+        children are global slots [child_begin, child_begin + n)); src: the genome words the parents
+        are read from — n_segments back-to-back arrays of n_per_segment drones (default: this
+        population's own genomes, one segment); elite: W x 4 genome words copied unmutated into
+        global child 0, or None."""
+        torch = _torch()
+        if self.n % 2:
+            raise ValueError("the generation step pairs slots (i, i+1): the shard size must be even")
+        fitness_all = fitness_all.to(device=self.device, dtype=torch.int32).contiguous()
+        n_total = fitness_all.numel()
+        src = self.genomes if src is None else src
+        n_per_segment = self.n if n_per_segment is None else int(n_per_segment)
+        n_layers = self.spec.n_hidden + 1
+        parents = torch.empty((self.n,), dtype=torch.int32, device=self.device)
+        cuts = torch.empty((max(self.n // 2, 1), n_layers), dtype=torch.int32, device=self.device)
+        lib = _native.lib()
+        _native.check(lib.ld_ga_select(C.byref(ga), C.byref(self.spec), self._ptr(fitness_all), n_total, child_begin,
+                                       self.n, self._ptr(parents), self._ptr(cuts), self._stream()), "ld_ga_select")
+        children = torch.empty_like(self.genomes)
+        if elite is not None:
+            elite = elite.to(device=self.device, dtype=self.dtype).contiguous()
+        _native.check(self._fn("ld_ga_breed")(C.byref(ga), C.byref(self.spec), self._ptr(src), n_per_segment, n_segments,
+                                              self._ptr(parents), self._ptr(cuts), self._ptr(elite), child_begin, self.n,
+                                              self._ptr(children), self._stream()), "ld_ga_breed")
+        self.genomes = children
+        self.last_parents, self.last_cuts = parents, cuts
 
     # ------------------------------------------------------------------ accounting
     @property

@@ -76,3 +76,122 @@ def test_evolve_two_generations(tmp_path):
     assert history[1][1] >= history[0][1]                    # the global best never decreases
     again = load_drone(str(ckpt))
     assert np.array_equal(again.genes, best.genes)
+
+
+# ------------------------------------------------------------------------------------------- device GA
+def _breed_once(n, hidden, fitness, ga, elite_slot=None, seed_genes=0):
+    import torch
+    from learning_drones_amd.population import Population
+    pop = Population(n, hidden)
+    rng = np.random.default_rng(seed_genes)
+    genes = rng.normal(0, 1, (n, pop.P)).astype(np.float32)
+    pop.set_genomes(genes)
+    elite = pop.genome_of(elite_slot) if elite_slot is not None else None
+    pop.breed(torch.as_tensor(fitness, dtype=torch.int32), ga, elite=elite)
+    torch.cuda.synchronize()
+    return genes, pop.get_genomes().cpu().numpy(), pop.last_parents.cpu().numpy(), pop.last_cuts.cpu().numpy(), pop
+
+
+def test_device_ga_selection_copies_parents():
+    """No crossover, no mutation: every child is an exact copy of its selected parent, the better of
+    a tournament wins with probability p_tournament, and slot 0 is the elite."""
+    from learning_drones_amd.params import GaParams
+    n, hidden = 4096, (10, 10)
+    fitness = np.random.default_rng(1).permutation(n).astype(np.int32)          # all distinct
+    ga = GaParams.reference(seed=7, generation=3, p_crossover=0.0, mutation_rate=0.0)
+    genes, children, parents, cuts, _ = _breed_once(n, hidden, fitness, ga, elite_slot=int(np.argmax(fitness)))
+    assert (cuts == -1).all()
+    assert np.array_equal(children[0], genes[np.argmax(fitness)])                # elitism
+    assert np.array_equal(children[1:], genes[parents[1:]])                      # exact copies
+    assert parents.min() >= 0 and parents.max() < n
+    # selection pressure: P(parent fitness rank in upper half) for a binary tournament with p = 0.6
+    # P(winner is the better of two) = 0.6  ->  E[rank quantile] = 0.6 * 2/3 + 0.4 * 1/3 = 0.5333
+    q = fitness[parents] / (n - 1)
+    assert abs(q.mean() - (0.6 * 2 / 3 + 0.4 / 3)) < 0.01
+    # a different generation or seed draws different parents; the same inputs reproduce them
+    again = _breed_once(n, hidden, fitness, ga)[2]
+    assert np.array_equal(again, parents)
+    other = _breed_once(n, hidden, fitness, GaParams.reference(seed=7, generation=4, p_crossover=0.0, mutation_rate=0.0))[2]
+    assert (other != parents).mean() > 0.9
+
+
+def test_device_ga_tie_rule():
+    """evolve/util.py:30-45: on equal fitness the second index wins when r < p, else the first —
+    so with all-equal fitness and p = 1 every tournament returns its second draw."""
+    from learning_drones_amd.params import GaParams
+    n = 1024
+    ga1 = GaParams.reference(seed=3, p_tournament=1.0, p_crossover=0.0, mutation_rate=0.0)
+    ga0 = GaParams.reference(seed=3, p_tournament=0.0, p_crossover=0.0, mutation_rate=0.0)
+    p1 = _breed_once(n, (10, 10), np.zeros(n, np.int32), ga1)[2]
+    p0 = _breed_once(n, (10, 10), np.zeros(n, np.int32), ga0)[2]
+    assert (p1 != p0).mean() > 0.99                                              # second vs first draw
+    fit = np.arange(n, dtype=np.int32)
+    best = _breed_once(n, (10, 10), fit, ga1)[2]
+    worst = _breed_once(n, (10, 10), fit, ga0)[2]
+    assert np.array_equal(np.sort(np.stack([best, worst]), axis=0)[1], best)     # p=1 picks the max of each pair
+
+
+def test_device_ga_crossover_structure():
+    """p_crossover = 1: per layer, child A = parent A before the cut and parent B from the cut on,
+    child B the mirror image (evolve/util.py:58-68)."""
+    from learning_drones_amd.params import GaParams, MlpSpec
+    n, hidden = 512, (16, 16)
+    spec = MlpSpec.from_hidden(hidden)
+    ga = GaParams.reference(seed=11, p_crossover=1.0, mutation_rate=0.0)
+    fitness = np.random.default_rng(2).integers(-5000, 5000, n).astype(np.int32)
+    genes, children, parents, cuts, _ = _breed_once(n, hidden, fitness, ga)
+    assert (cuts >= 0).all()
+    sizes = [a * b for a, b in spec.layer_shapes]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    for c in range(n):
+        a, b = genes[parents[c]], genes[parents[c ^ 1]]
+        want = a.copy()
+        for l, size in enumerate(sizes):
+            cut = cuts[c // 2, l]
+            assert 0 <= cut < size
+            want[offs[l] + cut:offs[l + 1]] = b[offs[l] + cut:offs[l + 1]]
+        assert np.array_equal(children[c], want), c
+    # rate check at the reference's p = 0.05 per layer
+    ga = GaParams.reference(seed=12, p_crossover=0.05, mutation_rate=0.0)
+    cuts = _breed_once(8192, hidden, np.zeros(8192, np.int32), ga)[3]
+    assert abs((cuts >= 0).mean() - 0.05) < 0.006
+    for l, size in enumerate(sizes):
+        got = cuts[:, l][cuts[:, l] >= 0]
+        assert got.min() >= 0 and got.max() < size
+
+
+def test_device_ga_mutation_statistics():
+    """Per-gene Bernoulli(0.05) x N(0, 0.3) (drone/drone.py:167-172)."""
+    from learning_drones_amd.params import GaParams
+    n, hidden = 2048, (32, 32)
+    ga = GaParams.reference(seed=5, p_crossover=0.0)
+    genes, children, parents, _, _ = _breed_once(n, hidden, np.zeros(n, np.int32), ga)
+    delta = (children - genes[parents]).astype(np.float64)
+    mutated = delta != 0
+    assert abs(mutated.mean() - 0.05) < 0.001
+    d = delta[mutated]
+    assert abs(d.mean()) < 0.002 and abs(d.std() - 0.3) < 0.003
+    assert abs(np.mean(np.abs(d) < 0.3) - 0.6827) < 0.005                         # Gaussian shape
+    assert abs(mutated.mean(axis=0).std() - np.sqrt(0.05 * 0.95 / n)) < 0.002    # no gene position favoured
+
+
+def test_device_evolution_loop():
+    """Whole loop on the device: the global best never decreases, slot 0 holds the unmutated global
+    best, and re-evaluating it next generation reproduces its score exactly (deterministic rollout)."""
+    import torch
+    from learning_drones_amd.parallel import DeviceEvolution, ShardedPopulation
+    pop = ShardedPopulation(2048, (16, 16))
+    pop.local.init_genomes_reference(seed=1)
+    evo = DeviceEvolution(pop, seed=42)
+    prev_global = None
+    for g in range(6):
+        best, gbest, records = evo.step(600)
+        if prev_global is not None:
+            assert int(records[0, 0]) == prev_global          # the elite flies exactly as before
+            assert best >= prev_global
+        assert torch.equal(pop.local.genome_of(0), evo.elite)     # slot 0 = global best, unmutated
+        assert not torch.equal(pop.local.genome_of(1), evo.elite)
+        prev_global = gbest
+    scores = [h[1] for h in evo.history]
+    assert scores == sorted(scores) and evo.generation == 6
+    assert int(pop.local.flight_time.sum()) == 0                   # children start reset

@@ -159,6 +159,27 @@ def main():
             traffic, traffic_src = prof["hbm_traffic_bytes_per_launch"], f"profiles/{f.name}"
             break
 
+    # generations/s of the whole loop on the device: rollout + all-gather of records + argmax/elite +
+    # all-gather of genome shards (N > 1) + select/breed kernels + state reset.  Mutated children of
+    # stable flyers crash early and frozen wavefronts skip their gene traffic, so this is faster than
+    # 1 / episode time; the live fraction of the measured generations is reported next to it.
+    from learning_drones_amd.parallel import DeviceEvolution
+    evo = DeviceEvolution(pop, seed=0x1D20)
+    pop.local.reset()
+    evo.step(T)
+    fence()
+    g0 = time.perf_counter()
+    n_gen, gen_live = 3, 0.0
+    for _ in range(n_gen):
+        _, _, rec = evo.step(T)
+        gen_live += float(rec[:, 1].double().sum().item()) / (rec.shape[0] * T) / n_gen
+    fence()
+    gen_dt = time.perf_counter() - g0
+    if dist:
+        tmax = torch.tensor([gen_dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        gen_dt = float(tmax.item())
+
     if rank == 0:
         n_total = n_local * world
         value = n_total * T * args.steps / dt
@@ -172,8 +193,12 @@ def main():
                                    f"({T} fused-step launches + finalize" + (" + RCCL all-gather of fitness records)" if world > 1 else ")"),
                        "population": n_total, "timesteps": T, "hidden": list(hidden), "coins": args.coins,
                        "parallelism": f"population sharded x{world}, no data-path collective inside the rollout"},
-            "generations_per_s": args.steps / dt,
+            "evaluations_per_s": args.steps / dt,
             "live_drone_step_fraction": live,
+            "generations_per_s": n_gen / gen_dt,
+            "generation": {"measured": n_gen, "includes": "rollout, record all-gather, elite, genome all-gather (N>1), "
+                           "device select+breed (evolve/util.py + Drone.mutate semantics), reset",
+                           "live_drone_step_fraction": gen_live},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "fly_step_kernel<float, UnrolledNet<32,32>>" if hidden == (32, 32) else "fly_step_kernel",

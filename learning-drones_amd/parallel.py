@@ -151,3 +151,35 @@ class DeviceEvolution:
         self.generation += 1
         self.history.append((best_score, self.global_best_score))
         return best_score, self.global_best_score, records
+
+    # ---- resume (the reference never saves the population, RNG state or generation counter,
+    # evolve/evolution.py:85-87; the Philox draws are keyed by (seed, generation), so these few
+    # values plus the genomes continue a run bit for bit)
+    def save(self, path: str) -> None:
+        import numpy as _np
+        pop = self.pop.local
+        _np.savez_compressed(path, generation=self.generation, seed=int(self.ga.seed),
+                             ga=_np.array([self.ga.p_tournament, self.ga.p_crossover, self.ga.mutation_rate,
+                                           self.ga.mutation_sigma]),
+                             global_best_score=-2**62 if self.global_best_score is None else self.global_best_score,
+                             elite=_np.zeros((0, 4)) if self.elite is None else self.elite.cpu().numpy(),
+                             history=_np.array(self.history, dtype=_np.int64).reshape(-1, 2),
+                             genes=pop.get_genomes().cpu().numpy(), rank=self.pop.rank, world=self.pop.world)
+
+    def load(self, path: str) -> None:
+        import numpy as _np
+        import torch
+        from .params import GaParams
+        z = _np.load(path, allow_pickle=False)
+        if int(z["world"]) != self.pop.world or int(z["rank"]) != self.pop.rank:
+            raise ValueError("checkpoint was written by a different rank / world size")
+        g = z["ga"]
+        self.ga = GaParams.reference(seed=int(z["seed"]), p_tournament=g[0], p_crossover=g[1], mutation_rate=g[2],
+                                     mutation_sigma=g[3])
+        self.generation = int(z["generation"])
+        gb = int(z["global_best_score"])
+        self.global_best_score = None if gb == -2**62 else gb
+        self.elite = None if len(z["elite"]) == 0 else torch.as_tensor(z["elite"]).to(self.pop.local.device, self.pop.local.dtype)
+        self.history = [tuple(int(v) for v in row) for row in z["history"]]
+        self.pop.local.set_genomes(z["genes"])
+        self.pop.local.reset()

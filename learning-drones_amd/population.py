@@ -271,6 +271,50 @@ class Population:
         self.genomes = children
         self.last_parents, self.last_cuts = parents, cuts
 
+    # ------------------------------------------------------------------ checkpoint / replay
+    def state_dict(self) -> dict:
+        """Everything needed to continue this population elsewhere (host numpy arrays)."""
+        return {"n": self.n, "hidden": np.array(self.spec.hidden_widths, np.int32), "precision": self.precision,
+                "genes": self.get_genomes().cpu().numpy(), "fstate": self.fstate.cpu().numpy(),
+                "istate": self.istate.cpu().numpy(), "records": self.records.cpu().numpy(),
+                "coins": self.coins_host, "walls": self.walls_host, "init_state": self.init_state,
+                "finalized": self._finalized}
+
+    def save(self, path: str) -> None:
+        np.savez_compressed(path, **self.state_dict())
+
+    @classmethod
+    def load(cls, path: str, device: Optional[str] = None) -> "Population":
+        torch = _torch()
+        z = np.load(path, allow_pickle=False)
+        pop = cls(int(z["n"]), tuple(int(h) for h in z["hidden"]), precision=str(z["precision"]), device=device,
+                  coins=z["coins"], walls=z["walls"] if len(z["walls"]) else None, init_state=z["init_state"])
+        pop.set_genomes(z["genes"])
+        pop.fstate.copy_(torch.from_numpy(z["fstate"]))
+        pop.istate.copy_(torch.from_numpy(z["istate"]))
+        pop.records.copy_(torch.from_numpy(z["records"]))
+        pop._finalized = bool(z["finalized"])
+        return pop
+
+    def record_trajectory(self, timesteps: int, slots: Sequence[int] = (0,)) -> np.ndarray:
+        """Fly `timesteps` steps (from the current state) and return the per-step log of the chosen
+        drones in the column order of the reference's Results.csv (datahandling/data_scraper.py:
+        300-307): time [s], roll, pitch, yaw [deg], x, y, z [m], thrust 1-4.  Shape
+        [len(slots), timesteps, 11]; rows after a crash repeat the frozen state."""
+        torch = _torch()
+        idx = torch.as_tensor(list(slots), device=self.device, dtype=torch.long)
+        log = torch.empty((int(timesteps), F_COUNT, len(idx)), dtype=self.dtype, device=self.device)
+        for t in range(int(timesteps)):
+            self.step()
+            log[t] = self.fstate.index_select(1, idx)
+        a = log.permute(2, 0, 1).double().cpu().numpy()
+        out = np.empty((len(idx), int(timesteps), 11))
+        out[:, :, 0] = np.arange(int(timesteps))[None, :] * float(self.sim.dt)
+        out[:, :, 1:4] = np.degrees(a[:, :, F_ANGLE:F_ANGLE + 3])
+        out[:, :, 4:7] = a[:, :, F_POS:F_POS + 3]
+        out[:, :, 7:11] = a[:, :, F_THRUST:F_THRUST + 4]
+        return out
+
     # ------------------------------------------------------------------ accounting
     @property
     def bytes_per_drone_step(self) -> int:

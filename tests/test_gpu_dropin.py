@@ -195,3 +195,65 @@ def test_device_evolution_loop():
     scores = [h[1] for h in evo.history]
     assert scores == sorted(scores) and evo.generation == 6
     assert int(pop.local.flight_time.sum()) == 0                   # children start reset
+
+
+def test_breed_from_gathered_segments():
+    """The multi-GPU generation step breeds from the all-gathered genome shards (n_segments arrays of
+    n_per_segment drones back to back); that addressing must give the same children as breeding from
+    one whole-population array."""
+    import torch
+    from learning_drones_amd.params import GaParams
+    from learning_drones_amd.population import Population
+    n, hidden, world = 512, (16, 16), 4
+    rng = np.random.default_rng(0)
+    whole = Population(n, hidden)
+    genes = rng.normal(0, 1, (n, whole.P)).astype(np.float32)
+    whole.set_genomes(genes)
+    fitness = torch.as_tensor(rng.integers(-4000, 4000, n).astype(np.int32))
+    ga = GaParams.reference(seed=9, generation=2, p_crossover=0.5)
+    elite = whole.genome_of(17)
+    whole.breed(fitness, ga, elite=elite)
+    want = whole.get_genomes().cpu().numpy()
+    shards = []
+    for r in range(world):
+        p = Population(n // world, hidden)
+        p.set_genomes(genes[r * (n // world):(r + 1) * (n // world)])
+        shards.append(p)
+    gathered = torch.stack([p.genomes for p in shards]).contiguous()      # what all_gather_into_tensor builds
+    got = []
+    for r, p in enumerate(shards):
+        p.breed(fitness, ga, elite=elite, child_begin=r * (n // world), src=gathered, n_per_segment=n // world,
+                n_segments=world)
+        got.append(p.get_genomes().cpu().numpy())
+    assert np.array_equal(np.concatenate(got), want)
+
+
+def test_checkpoint_resume_and_replay(tmp_path):
+    import torch
+    from learning_drones_amd.parallel import DeviceEvolution, ShardedPopulation
+    from learning_drones_amd.population import Population
+    pop = ShardedPopulation(256, (10, 10))
+    pop.local.init_genomes_reference(seed=3)
+    evo = DeviceEvolution(pop, seed=5)
+    for _ in range(2):
+        evo.step(300)
+    evo.save(str(tmp_path / "evo.npz"))
+    a = [evo.step(300)[:2] for _ in range(2)]
+    genes_a = pop.local.get_genomes().cpu().numpy()
+    pop2 = ShardedPopulation(256, (10, 10))
+    evo2 = DeviceEvolution(pop2)
+    evo2.load(str(tmp_path / "evo.npz"))
+    b = [evo2.step(300)[:2] for _ in range(2)]
+    assert a == b and np.array_equal(pop2.local.get_genomes().cpu().numpy(), genes_a)      # bit-exact resume
+    # population checkpoint mid-episode, then replay log in the reference's Results.csv column order
+    p = Population(8, (10, 10))
+    p.init_genomes_reference(seed=1)
+    for _ in range(50):
+        p.step()
+    p.save(str(tmp_path / "pop.npz"))
+    q = Population.load(str(tmp_path / "pop.npz"))
+    log_p, log_q = p.record_trajectory(100, slots=(0, 5)), q.record_trajectory(100, slots=(0, 5))
+    assert np.array_equal(log_p, log_q) and log_p.shape == (2, 100, 11)
+    assert np.allclose(log_p[0, :, 0], np.arange(100) * 0.01)
+    assert np.allclose(log_p[1, -1, 4:7], p.position[:, 5].double().cpu().numpy())
+    assert torch.equal(p.fstate, q.fstate) and torch.equal(p.istate, q.istate)

@@ -23,13 +23,18 @@
  *     wavefront owns drone i):
  *       fstate  Real[LD_F_COUNT][n]   field-major, see enum ld_ffield
  *       istate  int32[LD_I_COUNT][n]  see enum ld_ifield
- *       genomes Real[ceil(P/4)][n][4] gene index p of drone i lives at
- *                                     ((p/4)*n + i)*4 + p%4, so that a lane
- *                                     streams 16-byte words and a wavefront
- *                                     streams 1 KiB lines.  Gene order p is the
- *                                     reference's: layers concatenated, each the
- *                                     row-major (n_out, n_in+1) matrix with the
- *                                     bias in the last column
+ *       genomes Real[ceil(n/64)][W][64][4]  W = ceil(P/4) words of four genes; gene
+ *                                     index p of drone i lives at
+ *                                     (((i/64)*W + p/4)*64 + i%64)*4 + p%4: the
+ *                                     array is blocked by wavefront, so a lane
+ *                                     streams 16-byte words, a wavefront streams
+ *                                     contiguous 1 KiB lines and its whole gene
+ *                                     stream is one contiguous W KiB region.  The
+ *                                     allocation is ld_genome_words(spec, n) words
+ *                                     (the last block is full-sized).  Gene order
+ *                                     p is the reference's: layers concatenated,
+ *                                     each the row-major (n_out, n_in+1) matrix
+ *                                     with the bias in the last column
  *                                     (evolve/brain.py:24, :45-46;
  *                                     evolve/util.py:56-57 flatten()).
  *     Real = float for *_f32 entry points, double for *_f64.
@@ -154,6 +159,8 @@ int ld_coin_chain_reference(double *coins_host, int32_t n_coins);
 int64_t ld_mlp_param_count(const ld_mlp_spec *spec);
 /* Number of 16-byte words per drone in the device genome layout = ceil(P/4). */
 int64_t ld_mlp_words_per_drone(const ld_mlp_spec *spec);
+/* Words (of 4 genes) a genome array for n drones must hold = ceil(n/64) * 64 * ceil(P/4). */
+int64_t ld_genome_words(const ld_mlp_spec *spec, int64_t n);
 
 /* Layout conversion between the reference's per-drone gene vector (row i = genes of drone i,
  * [n][P] row-major, what Drone.controller.weights flattens to) and the device genome layout.
@@ -247,9 +254,10 @@ int ld_ga_select(const ld_ga_params *ga, const ld_mlp_spec *spec, const int32_t 
  * partner's parent per layer (evolve/util.py:58-68), then per-gene Bernoulli(mutation_rate) *
  * N(0, mutation_sigma) (drone/drone.py:167-172).  src holds n_segments back-to-back genome arrays of
  * n_per_segment drones each (the all-gathered shards; 1 segment on a single GPU); global parent g
- * lives in segment g / n_per_segment, slot g % n_per_segment.  If elite != NULL (device, W words of
+ * lives in segment g / n_per_segment, slot g % n_per_segment; each segment is a whole genome array of
+ * ld_genome_words(spec, n_per_segment) words.  If elite != NULL (device, W words of
  * one genome) global child 0 becomes an unmutated copy of it (evolve/evolution.py:105-107).
- * dst is the children's genome array [W][n_children][4]; it must not alias src. */
+ * dst is the children's genome array (n_children drones, same blocked layout); it must not alias src. */
 int ld_ga_breed_f32(const ld_ga_params *ga, const ld_mlp_spec *spec, const float *src, int64_t n_per_segment,
                     int32_t n_segments, const int32_t *parents, const int32_t *cuts, const float *elite,
                     int64_t child_begin, int64_t n_children, float *dst, void *stream);

@@ -19,6 +19,7 @@ LIB_PATH = PKG_DIR / "libld_drones.so"
 EXPORTS = (
     "ld_version", "ld_strerror", "ld_last_hip_error", "ld_device_count", "ld_sim_params_default",
     "ld_episode_params_default", "ld_coin_chain_reference", "ld_mlp_param_count", "ld_mlp_words_per_drone",
+    "ld_genome_words",
     "ld_genomes_pack_f32", "ld_genomes_unpack_f32", "ld_genomes_pack_f64", "ld_genomes_unpack_f64",
     "ld_population_reset_f32", "ld_population_reset_f64", "ld_measure_f32", "ld_measure_f64",
     "ld_mlp_forward_f32", "ld_mlp_forward_f64", "ld_fly_step_f32", "ld_fly_step_f64",
@@ -75,6 +76,8 @@ def _declare(h: C.CDLL) -> None:
     h.ld_mlp_param_count.argtypes = [spec]
     h.ld_mlp_words_per_drone.restype = i64
     h.ld_mlp_words_per_drone.argtypes = [spec]
+    h.ld_genome_words.restype = i64
+    h.ld_genome_words.argtypes = [spec, i64]
     for sfx in ("f32", "f64"):
         getattr(h, f"ld_genomes_pack_{sfx}").argtypes = [vp, i64, vp, i64, i64, vp]
         getattr(h, f"ld_genomes_unpack_{sfx}").argtypes = [vp, vp, i64, i64, i64, vp]
@@ -91,7 +94,8 @@ def _declare(h: C.CDLL) -> None:
     h.ld_ga_breed_f32.argtypes = [ga, spec, vp, i64, i32, vp, vp, vp, i64, i64, vp, vp]
     h.ld_ga_breed_f64.argtypes = [ga, spec, vp, i64, i32, vp, vp, vp, i64, i64, vp, vp]
     for name in EXPORTS:
-        if name not in ("ld_strerror", "ld_last_hip_error", "ld_mlp_param_count", "ld_mlp_words_per_drone"):
+        if name not in ("ld_strerror", "ld_last_hip_error", "ld_mlp_param_count", "ld_mlp_words_per_drone",
+                        "ld_genome_words"):
             getattr(h, name).restype = C.c_int
 
 

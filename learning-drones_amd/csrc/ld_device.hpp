@@ -218,15 +218,41 @@ template <typename Real> __device__ __forceinline__ Real sigmoid04(Real v)
 
 // ---------------------------------------------------------------------------------------------
 // Genome words.  A drone's genes are stored as 16-byte (float) / 32-byte (double) words of four
-// consecutive genes; word w of drone i sits at genomes[w * n + i], so a wavefront's load of one
-// word index is one contiguous 1 KiB (float) line.
+// consecutive genes.  The array is blocked by wavefront: drones [64b, 64b+64) own the contiguous
+// block  genomes[b][W][64]  (W words each), so the 64 lanes of a wavefront read one contiguous
+// 1 KiB (float) line per word and a wavefront's whole gene stream is ONE contiguous W KiB region
+// (sequential DRAM pages, one or two TLB entries per wavefront).  A word-major [W][n] layout puts
+// consecutive words of a wavefront n*16 bytes apart: every load of the 16 in flight touches
+// another 2 MiB page, which cost 20-25 % of the bandwidth above one wavefront per SIMD.
 // ---------------------------------------------------------------------------------------------
 template <typename Real> struct alignas(4 * sizeof(Real)) GeneWord { Real g[4]; };
 
-template <typename Real>
-__device__ __forceinline__ GeneWord<Real> load_word(const GeneWord<Real>* __restrict__ lane_base, int64_t n, int w)
+constexpr int kGenomeBlock = 64;          // drones per genome block = lanes per wavefront
+
+// index (in words) of word w of drone i
+__host__ __device__ inline int64_t word_index(int64_t i, int64_t w, int64_t W)
 {
-    return lane_base[(int64_t)w * n];
+    return ((i / kGenomeBlock) * W + w) * kGenomeBlock + (i % kGenomeBlock);
+}
+
+// LD_GENE_NT=1 streams genes with the non-temporal hint (each word is read once per launch).
+#ifndef LD_GENE_NT
+#define LD_GENE_NT 1
+#endif
+// lane_offset = word_index(i, 0, W)
+template <typename Real>
+__device__ __forceinline__ GeneWord<Real> load_word(const GeneWord<Real>* __restrict__ genomes, int64_t lane_offset, int w)
+{
+    const GeneWord<Real>* p = genomes + lane_offset + (int64_t)w * kGenomeBlock;
+#if LD_GENE_NT
+    using V = __attribute__((ext_vector_type(4))) Real;
+    const V v = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+    GeneWord<Real> r;
+    r.g[0] = v.x; r.g[1] = v.y; r.g[2] = v.z; r.g[3] = v.w;
+    return r;
+#else
+    return *p;
+#endif
 }
 
 }  // namespace ld

@@ -96,12 +96,13 @@ ga_breed_kernel(const ld_ga_params ga, const LayerTable lt, const GeneWord<Real>
     const int64_t w = t / n_children, c = t % n_children;
     const int64_t gchild = child_begin + c;
     if (elite != nullptr && gchild == 0) {                                // evolution.py:105-107
-        dst[w * n_children + c] = elite[w];
+        dst[word_index(c, w, W)] = elite[w];
         return;
     }
+    const int64_t blocks_per_segment = (n_per_segment + kGenomeBlock - 1) / kGenomeBlock;
     auto word_of = [&](int64_t g) {
         const int64_t seg = g / n_per_segment, slot = g % n_per_segment;
-        return src[(seg * W + w) * n_per_segment + slot];
+        return src[seg * blocks_per_segment * W * kGenomeBlock + word_index(slot, w, W)];
     };
     const int32_t pa = parents[c], pb = parents[c ^ 1];
     GeneWord<Real> v = word_of(pa);
@@ -142,7 +143,7 @@ ga_breed_kernel(const ld_ga_params ga, const LayerTable lt, const GeneWord<Real>
             v.g[j] = v.g[j] + (Real)((float)ga.mutation_sigma * nrm);
         }
     }
-    dst[w * n_children + c] = v;
+    dst[word_index(c, w, W)] = v;
 }
 
 }  // namespace ld

@@ -4,10 +4,12 @@
 //   fstate  Real [22][n]   field-major SoA: lane i of a wavefront reads drone i, every access of a
 //                          field is one coalesced 256-byte (float) line per wavefront
 //   istate  int32[3][n]    reward, coins, 2*flight_time + crashed
-//   genomes GeneWord[W][n] W = ceil(P/4) 16-byte words per drone, word-major: a wavefront's load
-//                          of word w is one contiguous 1 KiB line; genes are read exactly once
-//                          per drone-step and never staged (no reuse to exploit: every drone has
-//                          its own genome, the controller is a batch of GEMVs at 0.5 flop/byte)
+//   genomes GeneWord[ceil(n/64)][W][64]  W = ceil(P/4) 16-byte words per drone, blocked by
+//                          wavefront: a wavefront's load of word w is one contiguous 1 KiB line
+//                          and its whole stream one contiguous W KiB region; genes are read
+//                          exactly once per drone-step and never staged (no reuse to exploit:
+//                          every drone has its own genome, the controller is a batch of GEMVs at
+//                          0.5 flop/byte)
 //   coins / walls          tiny uniform tables (double), staged once per workgroup in LDS
 //
 // The fused step kernel advances the whole population one timestep per launch.  Its algorithmic
@@ -81,7 +83,8 @@ fly_step_kernel(const ld_sim_params sim, const ld_episode_params ep, const ld_ml
     // Issue every independent load first: status, genome prefetch, state, tables.
     const int32_t status = istate[(int64_t)LD_I_STATUS * n + i];
     typename Net::Ring ring;
-    Net::prefetch(spec, genomes + i, n, ring);
+    const int64_t lane_offset = word_index(i, 0, Net::words(spec));
+    Net::prefetch(spec, genomes, lane_offset, ring);
     int32_t reward = istate[(int64_t)LD_I_REWARD * n + i];
     int32_t ncoll = istate[(int64_t)LD_I_COINS * n + i];
     DroneRegs<Real> d;
@@ -110,7 +113,7 @@ fly_step_kernel(const ld_sim_params sim, const ld_episode_params ep, const ld_ml
     for (int k = 0; k < 12; ++k) x[k] = d.s[k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) x[12 + k] = tab.coins[cur * LD_COIN_STRIDE + k];
-    Net::forward(spec, net_lds, genomes, i, n, ring, x, y);
+    Net::forward(spec, net_lds, genomes, lane_offset, ring, x, y);
     // a select, not a branch: under `if (!crashed)` the compiler sinks the output layer and its
     // gene loads into the conditional block, past the pinned pipeline
 #pragma unroll
@@ -155,11 +158,12 @@ mlp_forward_kernel(const ld_mlp_spec spec, const GeneWord<Real>* __restrict__ ge
     const bool valid = gid < n;
     const int64_t i = valid ? gid : n - 1;
     typename Net::Ring ring;
-    Net::prefetch(spec, genomes + i, n, ring);
+    const int64_t lane_offset = word_index(i, 0, Net::words(spec));
+    Net::prefetch(spec, genomes, lane_offset, ring);
     Real x[LD_N_INPUTS], y[LD_N_OUTPUTS];
 #pragma unroll
     for (int k = 0; k < LD_N_INPUTS; ++k) x[k] = inputs[(int64_t)k * n + i];
-    Net::forward(spec, net_lds, genomes, i, n, ring, x, y);
+    Net::forward(spec, net_lds, genomes, lane_offset, ring, x, y);
     if (valid) {
 #pragma unroll
         for (int k = 0; k < LD_N_OUTPUTS; ++k) outputs[(int64_t)k * n + i] = y[k];
@@ -214,7 +218,7 @@ reset_kernel(Real* __restrict__ fstate, int32_t* __restrict__ istate, const int6
     for (int f = 0; f < LD_I_COUNT; ++f) istate[(int64_t)f * n + i] = 0;
 }
 
-// Gene-vector rows [n][P] <-> device genome words [W][n][4].  Each thread moves one word.
+// Gene-vector rows [n][P] <-> device genome words [n/64][W][64][4].  Each thread moves one word.
 template <typename Real, bool Pack>
 __global__ void __launch_bounds__(256)
 genome_layout_kernel(Real* __restrict__ rows, const int64_t row_stride, GeneWord<Real>* __restrict__ genomes,
@@ -228,9 +232,9 @@ genome_layout_kernel(Real* __restrict__ rows, const int64_t row_stride, GeneWord
         GeneWord<Real> v;
 #pragma unroll
         for (int c = 0; c < 4; ++c) v.g[c] = (4 * w + c < P) ? rows[i * row_stride + 4 * w + c] : (Real)0;
-        genomes[w * n + i] = v;
+        genomes[word_index(i, w, W)] = v;
     } else {
-        const GeneWord<Real> v = genomes[w * n + i];
+        const GeneWord<Real> v = genomes[word_index(i, w, W)];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             if (4 * w + c < P) rows[i * row_stride + 4 * w + c] = v.g[c];
@@ -563,6 +567,14 @@ int64_t ld_mlp_words_per_drone(const ld_mlp_spec* spec)
 {
     const int64_t P = ld_mlp_param_count(spec);
     return P < 0 ? P : (P + 3) / 4;
+}
+
+int64_t ld_genome_words(const ld_mlp_spec* spec, int64_t n)
+{
+    const int64_t W = ld_mlp_words_per_drone(spec);
+    if (W < 0) return W;
+    if (n < 0) return LD_ERR_SIZE;
+    return (n + ld::kGenomeBlock - 1) / ld::kGenomeBlock * ld::kGenomeBlock * W;
 }
 
 int ld_genomes_pack_f32(const float* rows, int64_t row_stride, float* genomes, int64_t n, int64_t P, void* stream)

@@ -19,6 +19,16 @@
 
 #include "ld_device.hpp"
 
+#ifndef LD_DEPTH_F32
+#define LD_DEPTH_F32 16
+#endif
+#ifndef LD_DEPTH_F64
+#define LD_DEPTH_F64 8
+#endif
+#ifndef LD_UNROLLED_BLOCK
+#define LD_UNROLLED_BLOCK 64
+#endif
+
 namespace ld {
 
 template <int B, typename F, int... Is>
@@ -82,24 +92,27 @@ template <int... H> struct NetShape {
 // ---------------------------------------------------------------------------------------------
 template <typename Real, bool Fma, int... H> struct UnrolledNet {
     using Shape = NetShape<H...>;
-    static constexpr int kBlock = 64;
+    static constexpr int kBlock = LD_UNROLLED_BLOCK;
     // words in flight per lane: 16 x 16 B (float) / 8 x 32 B (double) = 16 KiB per wavefront
-    static constexpr int kDepth = (sizeof(Real) == 4 ? 16 : 8) < Shape::W ? (sizeof(Real) == 4 ? 16 : 8) : Shape::W;
+    static constexpr int kWant = sizeof(Real) == 4 ? LD_DEPTH_F32 : LD_DEPTH_F64;
+    static constexpr int kDepth = kWant < Shape::W ? kWant : Shape::W;
     struct Lds {};                               // no LDS use
     struct Ring { GeneWord<Real> slot[kDepth]; };
 
     // Issue the first kDepth word loads; nothing waits on them until forward().
-    static __device__ __forceinline__ void prefetch(const ld_mlp_spec&, const GeneWord<Real>* __restrict__ lane_base,
-                                                    int64_t n, Ring& ring)
+    static __device__ __forceinline__ int words(const ld_mlp_spec&) { return Shape::W; }
+
+    static __device__ __forceinline__ void prefetch(const ld_mlp_spec&, const GeneWord<Real>* __restrict__ genomes,
+                                                    int64_t lane_offset, Ring& ring)
     {
         static_for<0, kDepth>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
-            ring.slot[i] = load_word<Real>(lane_base, n, i);
+            ring.slot[i] = load_word<Real>(genomes, lane_offset, i);
         });
     }
 
     static __device__ __forceinline__ void forward(const ld_mlp_spec&, Lds&, const GeneWord<Real>* __restrict__ genomes,
-                                                   int64_t i, int64_t n, Ring& ring, const Real (&x)[LD_N_INPUTS],
+                                                   int64_t lane_offset, Ring& ring, const Real (&x)[LD_N_INPUTS],
                                                    Real (&y)[LD_N_OUTPUTS])
     {
         constexpr int MW = Shape::max_width();
@@ -134,8 +147,8 @@ template <typename Real, bool Fma, int... H> struct UnrolledNet {
                 }
             });
             if constexpr (w + kDepth < Shape::W) {
-                asm volatile("" : "+v"(i) : "v"(acc));      // (the pointer itself would decay to flat)
-                ring.slot[w % kDepth] = load_word<Real>(genomes + i, n, w + kDepth);
+                asm volatile("" : "+v"(lane_offset) : "v"(acc));      // (the pointer itself would decay to flat)
+                ring.slot[w % kDepth] = load_word<Real>(genomes, lane_offset, w + kDepth);
             }
         });
 #pragma unroll
@@ -164,19 +177,20 @@ template <typename Real, bool Fma> struct GenericNet {
         return P + (int64_t)LD_N_OUTPUTS * (n_in + 1);
     }
 
-    static __device__ __forceinline__ void prefetch(const ld_mlp_spec& s, const GeneWord<Real>* __restrict__ lane_base,
-                                                    int64_t n, Ring& ring)
+    static __device__ __forceinline__ int words(const ld_mlp_spec& s) { return (int)((param_count(s) + 3) / 4); }
+
+    static __device__ __forceinline__ void prefetch(const ld_mlp_spec& s, const GeneWord<Real>* __restrict__ genomes,
+                                                    int64_t lane_offset, Ring& ring)
     {
-        const int W = (int)((param_count(s) + 3) / 4);
+        const int W = words(s);
 #pragma unroll
-        for (int i = 0; i < kDepth; ++i) ring.slot[i] = load_word<Real>(lane_base, n, i < W ? i : W - 1);
+        for (int i = 0; i < kDepth; ++i) ring.slot[i] = load_word<Real>(genomes, lane_offset, i < W ? i : W - 1);
     }
 
     static __device__ __forceinline__ void forward(const ld_mlp_spec& s, Lds& lds, const GeneWord<Real>* __restrict__ genomes,
-                                                   int64_t i_drone, int64_t n, Ring& ring, const Real (&x)[LD_N_INPUTS],
+                                                   int64_t lane_offset, Ring& ring, const Real (&x)[LD_N_INPUTS],
                                                    Real (&y)[LD_N_OUTPUTS])
     {
-        const GeneWord<Real>* __restrict__ lane_base = genomes + i_drone;
         const int lane = threadIdx.x;
         const int P = (int)param_count(s);
         const int W = (P + 3) / 4;
@@ -191,7 +205,7 @@ template <typename Real, bool Fma> struct GenericNet {
                 const int w = w0 + i;
                 if (w >= W) break;
                 const GeneWord<Real> v = ring.slot[i];
-                ring.slot[i] = load_word<Real>(lane_base, n, (w + kDepth < W) ? w + kDepth : W - 1);
+                ring.slot[i] = load_word<Real>(genomes, lane_offset, (w + kDepth < W) ? w + kDepth : W - 1);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     if (4 * w + c >= P) break;

@@ -22,6 +22,7 @@ MAX_COINS = 64
 COIN_STRIDE = 5
 MAX_WALLS = 16
 WALL_STRIDE = 6
+GENOME_BLOCK = 64        # drones per genome block (= wavefront width), ld_device.hpp kGenomeBlock
 
 # fstate / istate field offsets (enum ld_ffield / ld_ifield)
 F_POS, F_VEL, F_ANGLE, F_ANGVEL, F_ACC, F_THRUST, F_COUNT = 0, 3, 6, 9, 12, 18, 22

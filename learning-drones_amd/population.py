@@ -18,7 +18,8 @@ import numpy as np
 
 from . import _native
 from .params import (COIN_STRIDE, CRASHED_BIT, F_ACC, F_ANGLE, F_ANGVEL, F_COUNT, F_POS, F_THRUST, F_VEL,
-                     FITNESS_DTYPE, I_COINS, I_COUNT, I_REWARD, I_STATUS, INITIAL_STATE, MAX_COINS, WALL_STRIDE,
+                     FITNESS_DTYPE, GENOME_BLOCK, I_COINS, I_COUNT, I_REWARD, I_STATUS, INITIAL_STATE, MAX_COINS,
+                     WALL_STRIDE,
                      EpisodeParams, GaParams, MlpSpec, SimParams, coin_chain_reference, flatten_weights,
                      unflatten_weights)
 
@@ -63,7 +64,8 @@ class Population:
         dev, n = self.device, self.n
         self.fstate = torch.zeros((F_COUNT, n), dtype=self.dtype, device=dev)
         self.istate = torch.zeros((I_COUNT, n), dtype=torch.int32, device=dev)
-        self.genomes = torch.zeros((W, n, 4), dtype=self.dtype, device=dev)
+        self.n_blocks = (n + GENOME_BLOCK - 1) // GENOME_BLOCK
+        self.genomes = torch.zeros((self.n_blocks, W, GENOME_BLOCK, 4), dtype=self.dtype, device=dev)
         self.records = torch.zeros((n, 4), dtype=torch.int32, device=dev)          # ld_fitness_record[n]
         self.distance = torch.zeros((n,), dtype=torch.float64, device=dev) if precision == "f64" else None
         self.coins_dev = torch.from_numpy(coins).to(dev)
@@ -237,7 +239,7 @@ class Population:
     # ------------------------------------------------------------------ generation step (device GA)
     def genome_of(self, slot: int):
         """The W x 4 genome words of one drone (device tensor; the elite buffer of breed())."""
-        return self.genomes[:, slot, :].contiguous()
+        return self.genomes[slot // GENOME_BLOCK, :, slot % GENOME_BLOCK, :].contiguous()
 
     def breed(self, fitness_all, ga: GaParams, *, elite=None, child_begin: int = 0, src=None,
               n_per_segment: Optional[int] = None, n_segments: int = 1) -> None:

@@ -10,11 +10,13 @@ Parity ladder:
       exact rewards / coins / flight times
   L4  populations: float32 kernels vs oracle float32, fraction of identical integer fitness
 """
+import ctypes as C
 import os
 
 import numpy as np
 import pytest
 
+from learning_drones_amd import _native
 from learning_drones_amd.params import EpisodeParams, MlpSpec, SimParams, coin_chain_reference
 
 pytestmark = pytest.mark.gpu
@@ -157,11 +159,12 @@ def test_genome_layout_roundtrip(Population, torch):
             back = pop.get_genomes().double().cpu().numpy()
             want = rows.astype(np.float32).astype(np.float64) if precision == "f32" else rows
             assert np.array_equal(back, want)
-            # documented layout: gene p of drone i at ((p/4)*n + i)*4 + p%4
+            # documented layout: gene p of drone i at (((i/64)*W + p/4)*64 + i%64)*4 + p%4
             flat = pop.genomes.double().cpu().numpy().ravel()
+            assert flat.size == _native.lib().ld_genome_words(C.byref(pop.spec), n) * 4
             for p in (0, 5, pop.P - 1):
-                for i in (0, n - 1):
-                    assert flat[((p // 4) * n + i) * 4 + p % 4] == want[i, p]
+                for i in (0, n // 2, n - 1):
+                    assert flat[(((i // 64) * pop.W + p // 4) * 64 + i % 64) * 4 + p % 4] == want[i, p]
 
 
 # ------------------------------------------------------------------------------------------- L3: closed loop, float64

@@ -36,10 +36,16 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 {
     (f(std::integral_constant<int, B + Is>{}), ...);
 }
-// f(integral_constant<int, i>) for i in [B, E), fully unrolled with compile-time i.
+// f(integral_constant<int, i>) for i in [B, E), fully unrolled with compile-time i (split into
+// chunks: clang caps a fold expression at 2048 operands).
 template <int B, int E, typename F> __device__ __forceinline__ void static_for(F&& f)
 {
-    if constexpr (E > B) static_for_impl<B>(f, std::make_integer_sequence<int, E - B>{});
+    if constexpr (E - B > 512) {
+        static_for<B, B + 512>(f);
+        static_for<B + 512, E>(f);
+    } else if constexpr (E > B) {
+        static_for_impl<B>(f, std::make_integer_sequence<int, E - B>{});
+    }
 }
 
 template <typename Real, bool Fma>

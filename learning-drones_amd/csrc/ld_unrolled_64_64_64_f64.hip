@@ -1,0 +1,4 @@
+#define LD_TAG 64_64_64
+#define LD_WIDTHS 64, 64, 64
+#define LD_ONLY_F64
+#include "ld_unrolled.inc"

@@ -18,7 +18,8 @@ fstate = torch.zeros((22, n), dtype=torch.float32, device=dev); istate = torch.z
 genomes = torch.zeros(((n + 63) // 64, W, 64, 4), dtype=torch.float32, device=dev)
 genomes2 = torch.zeros_like(genomes) if alt else genomes
 vp = C.c_void_p
-handles = {path.split('/')[-1]: C.CDLL(path) for path in libs}
+import os
+handles = {path.split('/')[-1]: C.CDLL(path.split(':')[0]) for path in libs}
 first = next(iter(handles.values()))
 stream = vp(torch.cuda.current_stream().cuda_stream)
 assert first.ld_genomes_pack_f32(vp(rows.data_ptr()), C.c_int64(P), vp(genomes.data_ptr()), C.c_int64(n), C.c_int64(P), stream) == 0
@@ -36,6 +37,8 @@ res = {k: [] for k in handles}
 L = 200
 for rnd in range(7):
     for name, h in handles.items():
+        if name.endswith(':generic'): os.environ['LD_FORCE_GENERIC'] = '1'
+        else: os.environ.pop('LD_FORCE_GENERIC', None)
         reset()
         for _ in range(10): step(h)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

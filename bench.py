@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--hidden", type=str, default=",".join(map(str, WORKLOAD["hidden"])))
     ap.add_argument("--coins", type=int, default=WORKLOAD["n_coins"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets several ranks share one "
+                    "GPU to rehearse the N > 1 control flow on a one-GPU box")
     args = ap.parse_args()
 
     import torch
@@ -90,13 +92,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from learning_drones_amd.parallel import ShardedPopulation
     from learning_drones_amd.params import coin_chain_reference

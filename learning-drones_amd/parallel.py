@@ -120,7 +120,8 @@ class DeviceEvolution:
             return local, self.pop.local.n, 1
         if self.pop.n_total % self.pop.world:
             raise ValueError("the device generation step needs equal shards (n_total divisible by the world size)")
-        out = torch.empty((self.pop.world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        out = torch.empty((self.pop.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
+                          device=local.device)      # shards back to back = the segments of ld_ga_breed
         dist.all_gather_into_tensor(out, local.contiguous(), group=self.pop.group)
         return out, self.pop.local.n, self.pop.world
 
@@ -130,8 +131,10 @@ class DeviceEvolution:
         pop = self.pop
         records = pop.fly(timesteps)                                  # rollout + all-gather of records
         fitness = records[:, 0].contiguous()
-        best_index = int(torch.argmax(fitness).item())                # first maximum, as np.argmax
-        best_score = int(fitness[best_index].item())
+        best_score = int(fitness.max().item())
+        # FIRST maximum, as np.argmax (evolution.py:77); torch.argmax does not promise which of several
+        # equal maxima it returns, and every rank must name the same owner for the broadcast below
+        best_index = int((fitness == best_score).nonzero()[0].item())
         if self.global_best_score is None or best_score > self.global_best_score:   # evolution.py:80-83
             self.global_best_score = best_score
             elite = torch.empty((pop.local.W, 4), dtype=pop.local.dtype, device=pop.local.device)

@@ -265,6 +265,23 @@ int ld_ga_breed_f64(const ld_ga_params *ga, const ld_mlp_spec *spec, const doubl
                     int32_t n_segments, const int32_t *parents, const int32_t *cuts, const double *elite,
                     int64_t child_begin, int64_t n_children, double *dst, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * BASELINE config 1 as a batched device policy: the PID-controlled episode of
+ * flight/collect_coins.py:261-364 — cascaded PID (drone/controller/pid.py:77-106,
+ * drone/onboard_computer.py:50-134) + the same physics/integrator — for n drones, each with its own
+ * 18 gains (order of choose_paramset.py:convert_paramset_2_float; Real[18][n], device).
+ * coins: device double[n_coins][3]; every coin has `coin_radius` and `coin_value` (1, 1000 in the
+ * reference).  The score starts at `timesteps`, loses 1 per step and gains coin_value per coin; the
+ * episode ends when the last coin is taken.  Outputs int32[n]: score, coins collected (target index),
+ * steps executed.  trace (optional, may be NULL): Real[timesteps][16][n] = state12 + thrust4 after
+ * every executed step.  The whole episode is one launch. */
+int ld_pid_episode_f32(const ld_sim_params *sim, const float *gains, const double *coins, int32_t n_coins,
+                       double coin_radius, int32_t coin_value, int32_t timesteps, float *fstate, int32_t *score,
+                       int32_t *target, int32_t *steps, float *trace, int64_t n, void *stream);
+int ld_pid_episode_f64(const ld_sim_params *sim, const double *gains, const double *coins, int32_t n_coins,
+                       double coin_radius, int32_t coin_value, int32_t timesteps, double *fstate, int32_t *score,
+                       int32_t *target, int32_t *steps, double *trace, int64_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,7 +24,7 @@ EXPORTS = (
     "ld_population_reset_f32", "ld_population_reset_f64", "ld_measure_f32", "ld_measure_f64",
     "ld_mlp_forward_f32", "ld_mlp_forward_f64", "ld_fly_step_f32", "ld_fly_step_f64",
     "ld_fly_finalize_f32", "ld_fly_finalize_f64", "ld_fly_rollout_f32", "ld_fly_rollout_f64",
-    "ld_ga_select", "ld_ga_breed_f32", "ld_ga_breed_f64",
+    "ld_ga_select", "ld_ga_breed_f32", "ld_ga_breed_f64", "ld_pid_episode_f32", "ld_pid_episode_f64",
 )
 
 
@@ -93,6 +93,8 @@ def _declare(h: C.CDLL) -> None:
     h.ld_ga_select.argtypes = [ga, spec, vp, i64, i64, i64, vp, vp, vp]
     h.ld_ga_breed_f32.argtypes = [ga, spec, vp, i64, i32, vp, vp, vp, i64, i64, vp, vp]
     h.ld_ga_breed_f64.argtypes = [ga, spec, vp, i64, i32, vp, vp, vp, i64, i64, vp, vp]
+    for sfx in ("f32", "f64"):
+        getattr(h, f"ld_pid_episode_{sfx}").argtypes = [sim, vp, vp, i32, C.c_double, i32, i32, vp, vp, vp, vp, vp, i64, vp]
     for name in EXPORTS:
         if name not in ("ld_strerror", "ld_last_hip_error", "ld_mlp_param_count", "ld_mlp_words_per_drone",
                         "ld_genome_words"):

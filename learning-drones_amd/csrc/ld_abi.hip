@@ -4,6 +4,7 @@
 
 #include "ld_ga.hpp"
 #include "ld_kernels.hpp"
+#include "ld_pid.hpp"
 
 using ld::blocks_for;
 using ld::check_launch;
@@ -194,9 +195,33 @@ int breed_impl(const ld_ga_params* ga, const ld_mlp_spec* spec, const Real* src,
     return check_launch("ga_breed_kernel");
 }
 
+template <typename Real, bool Faithful>
+int pid_impl(const ld_sim_params* sim, const Real* gains, const double* coins, int32_t n_coins, double coin_radius,
+             int32_t coin_value, int32_t timesteps, Real* fstate, int32_t* score, int32_t* target, int32_t* steps,
+             Real* trace, int64_t n, void* stream)
+{
+    if (!sim) return LD_ERR_NULL;
+    if (n < 0 || timesteps < 0 || n_coins < 1) return LD_ERR_SIZE;
+    if (n == 0) return LD_OK;
+    if (!gains || !coins || !fstate || !score || !target || !steps) return LD_ERR_NULL;
+    hipLaunchKernelGGL((ld::pid_episode_kernel<Real, Faithful>), dim3(blocks_for(n, 64)), dim3(64), 0,
+                       static_cast<hipStream_t>(stream), *sim, gains, coins, n_coins, coin_radius, coin_value, timesteps,
+                       fstate, score, target, steps, trace, n);
+    return check_launch("pid_episode_kernel");
+}
+
 }  // namespace
 
 extern "C" {
+
+int ld_pid_episode_f32(const ld_sim_params* sim, const float* gains, const double* coins, int32_t n_coins,
+                       double coin_radius, int32_t coin_value, int32_t timesteps, float* fstate, int32_t* score,
+                       int32_t* target, int32_t* steps, float* trace, int64_t n, void* stream)
+{ return pid_impl<float, false>(sim, gains, coins, n_coins, coin_radius, coin_value, timesteps, fstate, score, target, steps, trace, n, stream); }
+int ld_pid_episode_f64(const ld_sim_params* sim, const double* gains, const double* coins, int32_t n_coins,
+                       double coin_radius, int32_t coin_value, int32_t timesteps, double* fstate, int32_t* score,
+                       int32_t* target, int32_t* steps, double* trace, int64_t n, void* stream)
+{ return pid_impl<double, true>(sim, gains, coins, n_coins, coin_radius, coin_value, timesteps, fstate, score, target, steps, trace, n, stream); }
 
 int ld_ga_select(const ld_ga_params* ga, const ld_mlp_spec* spec, const int32_t* fitness, int64_t n_total,
                  int64_t child_begin, int64_t n_children, int32_t* parents, int32_t* cuts, void* stream)

@@ -257,3 +257,32 @@ def test_checkpoint_resume_and_replay(tmp_path):
     assert np.allclose(log_p[0, :, 0], np.arange(100) * 0.01)
     assert np.allclose(log_p[1, -1, 4:7], p.position[:, 5].double().cpu().numpy())
     assert torch.equal(p.fstate, q.fstate) and torch.equal(p.istate, q.istate)
+
+
+# ------------------------------------------------------------------------------------------- config 1 on the device (8f-4)
+def test_pid_policy_matches_reference_episodes(g4):
+    """All ten gain sets of choose_paramset.py as one batch; the three recorded in golden G4 must
+    reproduce the reference's trajectories, scores and coin counts (float64 kernels), and config 1
+    (paramset "11", 1000 steps) must end with score 3000 and 3 coins."""
+    from learning_drones_amd.pid import pid_episodes
+    names = [str(s) for s in g4["paramset_names"]]
+    out = pid_episodes(g4["paramsets"], 1600, coins=g4["coins"], precision="f64", trace=True)
+    for name in ("00", "11", "22"):
+        k = names.index(name)
+        S, U = g4[f"state_{name}"], g4[f"thrust_{name}"]
+        steps = int(out["steps"][k])
+        assert steps == len(S)
+        tr = out["trace"][:steps, k, :]
+        # closed loop over ~1 500 steps; the derivative term (kd * diff / dt) amplifies the few-ulp
+        # differences between device and glibc sin/cos/tan
+        assert np.max(np.abs(tr[:, :12] - S)) < 1e-7 and np.max(np.abs(tr[:, 12:] - U)) < 1e-7
+        # these episodes end by taking the last coin in the iteration after the last recorded step
+        assert steps < 1600 and int(out["score"][k]) == int(g4[f"score_{name}"][-1]) - 1 + 1000
+        assert int(out["coins"][k]) == int(g4[f"target_{name}"][-1]) == 3
+    cfg1 = pid_episodes(g4["paramsets"][names.index("11")][None], 1000, coins=g4["coins"], precision="f64")
+    assert [int(cfg1["score"][0]), int(cfg1["coins"][0]), int(cfg1["steps"][0])] == [int(v) for v in g4["cfg1_final"]]
+    # float32 policy: same coin counts, trajectory within the float32 open-loop envelope early on
+    f32 = pid_episodes(g4["paramsets"], 1600, coins=g4["coins"], precision="f32", trace=True)
+    k = names.index("11")
+    assert np.max(np.abs(f32["trace"][:300, k, :3] - g4["state_11"][:300, :3])) < 1e-2
+    assert np.array_equal(f32["coins"], out["coins"])

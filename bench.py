@@ -165,6 +165,28 @@ def main():
             traffic, traffic_src = prof["hbm_traffic_bytes_per_launch"], f"profiles/{f.name}"
             break
 
+    # The genome-resident engine (one launch per episode, genes held in registers: beyond the contract
+    # of "one launch per timestep", bit-identical results) on the same workload, for reference.
+    resident = None
+    if hidden in pop.local.RESIDENT_SPECS:
+        pop.local.reset()
+        pop.fly(T, engine="resident")
+        fence()
+        r0 = time.perf_counter()
+        for _ in range(args.steps):
+            pop.local.reset()
+            pop.fly(T, engine="resident")
+        fence()
+        rdt = time.perf_counter() - r0
+        if dist:
+            tmax = torch.tensor([rdt], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            rdt = float(tmax.item())
+        resident = {"value": n_local * world * T * args.steps / rdt, "unit": "drone-steps/s", "ms_per_step": rdt / args.steps * 1e3,
+                    "speedup_over_step_engine": dt / rdt,
+                    "note": "ld_fly_rollout_resident_f32: whole episode in one launch, genome in VGPRs (VALU-bound, "
+                            "HBM traffic ~1/T of the step engine); not the kernel the roofline object describes"}
+
     # generations/s of the whole loop on the device: rollout + all-gather of records + argmax/elite +
     # all-gather of genome shards (N > 1) + select/breed kernels + state reset.  Mutated children of
     # stable flyers crash early and frozen wavefronts skip their gene traffic, so this is faster than
@@ -201,9 +223,11 @@ def main():
                        "parallelism": f"population sharded x{world}, no data-path collective inside the rollout"},
             "evaluations_per_s": args.steps / dt,
             "live_drone_step_fraction": live,
+            "resident_engine": resident,
             "generations_per_s": n_gen / gen_dt,
             "generation": {"measured": n_gen, "includes": "rollout, record all-gather, elite, genome all-gather (N>1), "
-                           "device select+breed (evolve/util.py + Drone.mutate semantics), reset",
+                           "device select+breed (evolve/util.py + Drone.mutate semantics), reset; rollout engine: "
+                           + evo.engine,
                            "live_drone_step_fraction": gen_live},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -224,6 +224,16 @@ int ld_fly_rollout_f64(const ld_sim_params *sim, const ld_episode_params *ep, co
                        double *fstate, int32_t *istate, ld_fitness_record *records,
                        double *distance_f64, int64_t n, int32_t timesteps, void *stream);
 
+/* fly(drone, timesteps) with the genome RESIDENT in registers for the whole episode (float32):
+ * ONE launch runs all `timesteps` iterations; each drone owns L lanes of a wavefront that share its
+ * neurons, so the genes are read from HBM once per episode instead of once per step.  Same
+ * arithmetic, bit-identical results to ld_fly_rollout_f32.  Available for the layer specs 10-10,
+ * 16-16, 32-32 and 64-64-64; any other spec returns LD_ERR_SPEC (use ld_fly_rollout_f32). */
+int ld_fly_rollout_resident_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
+                                const double *coins, const double *walls, const float *genomes, float *fstate,
+                                int32_t *istate, ld_fitness_record *records, int64_t n, int32_t timesteps,
+                                void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Generation step on the device: the GA operators of evolve/util.py:5-78 and
  * Drone.mutate (drone/drone.py:167-172) applied to the device genome layout.  Random numbers come

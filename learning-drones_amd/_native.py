@@ -25,6 +25,7 @@ EXPORTS = (
     "ld_mlp_forward_f32", "ld_mlp_forward_f64", "ld_fly_step_f32", "ld_fly_step_f64",
     "ld_fly_finalize_f32", "ld_fly_finalize_f64", "ld_fly_rollout_f32", "ld_fly_rollout_f64",
     "ld_ga_select", "ld_ga_breed_f32", "ld_ga_breed_f64", "ld_pid_episode_f32", "ld_pid_episode_f64",
+    "ld_fly_rollout_resident_f32",
 )
 
 
@@ -89,6 +90,7 @@ def _declare(h: C.CDLL) -> None:
     h.ld_fly_finalize_f64.argtypes = [ep, vp, vp, vp, vp, vp, i64, vp]
     h.ld_fly_rollout_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, i64, i32, vp]
     h.ld_fly_rollout_f64.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]
+    h.ld_fly_rollout_resident_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, i64, i32, vp]
     ga = C.POINTER(GaParams)
     h.ld_ga_select.argtypes = [ga, spec, vp, i64, i64, i64, vp, vp, vp]
     h.ld_ga_breed_f32.argtypes = [ga, spec, vp, i64, i32, vp, vp, vp, i64, i64, vp, vp]

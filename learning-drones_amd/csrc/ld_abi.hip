@@ -6,6 +6,9 @@
 #include "ld_kernels.hpp"
 #include "ld_pid.hpp"
 
+int ld_resident_dispatch(const ld_sim_params*, const ld_episode_params*, const ld_mlp_spec*, const double*, const double*,
+                         const float*, float*, int32_t*, int64_t, int32_t, hipStream_t);          // ld_resident.hip
+
 using ld::blocks_for;
 using ld::check_launch;
 using ld::hip_fail;
@@ -213,6 +216,25 @@ int pid_impl(const ld_sim_params* sim, const Real* gains, const double* coins, i
 }  // namespace
 
 extern "C" {
+
+int ld_fly_rollout_resident_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,
+                                const double* coins, const double* walls, const float* genomes, float* fstate,
+                                int32_t* istate, ld_fitness_record* records, int64_t n, int32_t timesteps, void* stream)
+{
+    if (!sim || !ep) return LD_ERR_NULL;
+    int rc = check_spec(spec);
+    if (rc) return rc;
+    if (n < 0 || timesteps < 0) return LD_ERR_SIZE;
+    if (n == 0) return LD_OK;
+    rc = check_episode(ep, coins, walls);
+    if (rc) return rc;
+    if (!genomes || !fstate || !istate) return LD_ERR_NULL;
+    if (!aligned16(genomes)) return LD_ERR_ALIGN;
+    rc = ld_resident_dispatch(sim, ep, spec, coins, walls, genomes, fstate, istate, n, timesteps,
+                              static_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    return finalize_impl<float>(ep, coins, fstate, istate, records, nullptr, n, stream);
+}
 
 int ld_pid_episode_f32(const ld_sim_params* sim, const float* gains, const double* coins, int32_t n_coins,
                        double coin_radius, int32_t coin_value, int32_t timesteps, float* fstate, int32_t* score,

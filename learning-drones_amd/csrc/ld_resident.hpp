@@ -1,0 +1,159 @@
+// ld_resident.hpp — whole-episode rollout with the genome resident in registers.
+//
+// The contract kernel (fly_step_kernel, one launch per timestep, one lane per drone) re-reads every
+// drone's 4P bytes of genes from HBM on every step: it is an HBM stream by construction and runs at
+// the HBM roofline.  An episode, however, applies the SAME genome for all T steps.  This kernel
+// gives each drone L lanes of a wavefront (64/L drones per wavefront), deals the neurons of every
+// layer round-robin over those L lanes, and keeps each lane's share of the genome in VGPRs for the
+// whole episode (32-32 controller, L = 16: 131 gene registers per lane).  The genome is read from
+// HBM once per episode instead of once per step; the per-step work is then VALU-bound:
+//   - every lane evaluates its neurons with the same fma chain in gene order as the contract
+//     kernel (so results are bit-identical to it),
+//   - a layer's outputs are exchanged through a per-wavefront LDS row (one write per neuron, n_out
+//     broadcast reads per lane),
+//   - the rigid-body step is computed redundantly by the L lanes of a drone (a SIMD executes all
+//     lanes anyway; only lane 0 of a group stores).
+// The T-step loop lives inside the kernel; a wavefront whose drones have all crashed leaves it.
+//
+// Reference semantics are exactly fly_step_kernel's (flight/__init__.py:39-89); see ld_kernels.hpp.
+#pragma once
+
+#include "ld_kernels.hpp"
+
+namespace ld {
+
+template <int L, int... H> struct ResidentLayout {
+    using Shape = NetShape<H...>;
+    static constexpr int kLanes = L;
+    static constexpr int kDrones = 64 / L;
+    static constexpr int slots(int layer) { return (Shape::dims[layer + 1] + L - 1) / L; }     // neurons per lane
+    static constexpr int reg_offset(int layer)
+    {
+        int r = 0;
+        for (int l = 0; l < layer; ++l) r += slots(l) * (Shape::dims[l] + 1);
+        return r;
+    }
+    static constexpr int kGeneRegs = reg_offset(Shape::n_layers);
+};
+
+template <int L, int... H>
+__global__ void __launch_bounds__(64)
+fly_resident_kernel(const ld_sim_params sim, const ld_episode_params ep, const double* __restrict__ coins,
+                    const double* __restrict__ walls, const float* __restrict__ genomes, float* __restrict__ fstate,
+                    int32_t* __restrict__ istate, const int64_t n, const int32_t timesteps)
+{
+    using Lay = ResidentLayout<L, H...>;
+    using Shape = typename Lay::Shape;
+    constexpr int G = Lay::kDrones;
+    constexpr int MW = Shape::max_width();
+    __shared__ Tables<float> tab;
+    __shared__ float xch[2][G][MW + 4];                   // layer outputs, ping-pong, one padded row per drone
+
+    const int lane = threadIdx.x, g = lane / L, l = lane % L;
+    const int64_t drone = (int64_t)blockIdx.x * G + g;
+    const bool valid = drone < n;
+    const int64_t i = valid ? drone : n - 1;
+
+    // ---- this lane's share of the genome -> registers (once per episode)
+    float genes[Lay::kGeneRegs];
+    static_for<0, Shape::n_layers>([&](auto lc) __attribute__((always_inline)) {
+        constexpr int layer = decltype(lc)::value;
+        constexpr int n_in = Shape::dims[layer], n_out = Shape::dims[layer + 1];
+        static_for<0, Lay::slots(layer)>([&](auto qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value;
+            const int j = l + q * L;
+            const int jj = j < n_out ? j : n_out - 1;                       // lanes without a neuron re-read the last row
+            static_for<0, n_in + 1>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                const int p = Shape::layer_offset(layer) + jj * (n_in + 1) + k;
+                genes[Lay::reg_offset(layer) + q * (n_in + 1) + k] = genomes[word_index(i, p >> 2, Shape::W) * 4 + (p & 3)];
+            });
+        });
+    });
+
+    int32_t status = istate[(int64_t)LD_I_STATUS * n + i];
+    int32_t reward = istate[(int64_t)LD_I_REWARD * n + i];
+    int32_t ncoll = istate[(int64_t)LD_I_COINS * n + i];
+    DroneRegs<float> d;
+    load_drone<float>(fstate, n, i, d);
+    stage_tables<float>(tab, ep, coins, walls);
+    __syncthreads();
+
+    bool dead = (status & 1) || !valid;
+    int32_t flight_time = status >> 1;
+    for (int32_t t = 0; t < timesteps; ++t) {
+        if (__all(dead)) break;
+        // ---- flight/__init__.py:41-52, :79 (identical to fly_step_kernel)
+        int32_t r = reward + ep.reward_time;
+        int32_t nc = ncoll;
+        if (nc < ep.n_coins) {
+            const float* c = tab.coins + nc * LD_COIN_STRIDE;
+            if (coin_distance<float>(c, d.s) < c[3]) { r += (int32_t)c[4]; nc += 1; }
+        }
+        DroneRegs<float> e = d;
+        const bool crashed = measure<float, false>(sim, ep, tab.walls, e, r);
+        const int cur = nc < ep.n_coins ? nc : ep.n_coins - 1;
+
+        // ---- controller (evolve/brain.py:41-54): lane l owns neurons l, l+L, ... of every layer
+        float act[MW];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) act[k] = e.s[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) act[12 + k] = tab.coins[cur * LD_COIN_STRIDE + k];
+        static_for<0, Shape::n_layers>([&](auto lc) __attribute__((always_inline)) {
+            constexpr int layer = decltype(lc)::value;
+            constexpr int n_in = Shape::dims[layer], n_out = Shape::dims[layer + 1];
+            constexpr bool last = layer == Shape::n_layers - 1;
+            static_for<0, Lay::slots(layer)>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int q = decltype(qc)::value;
+                constexpr int base = Lay::reg_offset(layer) + q * (n_in + 1);
+                float acc = mac<float, true>(genes[base], act[0], 0.0f);
+                static_for<1, n_in>([&](auto kc) __attribute__((always_inline)) {
+                    constexpr int k = decltype(kc)::value;
+                    acc = mac<float, true>(genes[base + k], act[k], acc);
+                });
+                acc = acc + genes[base + n_in];
+                const float y = last ? sigmoid04<float>(acc) : relu<float>(acc);
+                const int j = l + q * L;
+                if (j < n_out) xch[layer & 1][g][j] = y;
+            });
+            __syncthreads();                               // one wavefront per workgroup: orders LDS write -> read
+#pragma unroll
+            for (int k = 0; k < n_out; ++k) act[k] = xch[layer & 1][g][k];
+        });
+        __syncthreads();                                   // the next step's first layer reuses buffer 0
+
+        if (!dead) {                                       // commit, as fly_step_kernel does
+#pragma unroll
+            for (int k = 0; k < 12; ++k) d.s[k] = e.s[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) d.acc[k] = e.acc[k];
+            if (!crashed) {
+#pragma unroll
+                for (int k = 0; k < LD_N_OUTPUTS; ++k) d.u[k] = act[k];
+            }
+            reward = r;
+            ncoll = nc;
+            flight_time += 1;
+            dead = crashed;
+        }
+    }
+    if (valid && l == 0) {
+        store_drone<float>(fstate, n, i, d);
+        istate[(int64_t)LD_I_REWARD * n + i] = reward;
+        istate[(int64_t)LD_I_COINS * n + i] = ncoll;
+        istate[(int64_t)LD_I_STATUS * n + i] = 2 * flight_time + (dead ? 1 : 0);
+    }
+}
+
+template <int L, int... H>
+int launch_fly_resident(const ld_sim_params* sim, const ld_episode_params* ep, const double* coins, const double* walls,
+                        const float* genomes, float* fstate, int32_t* istate, int64_t n, int32_t timesteps, hipStream_t stream)
+{
+    constexpr int G = 64 / L;
+    hipLaunchKernelGGL((fly_resident_kernel<L, H...>), dim3(blocks_for(n, G)), dim3(64), 0, stream, *sim, *ep, coins, walls,
+                       genomes, fstate, istate, n, timesteps);
+    return check_launch("fly_resident_kernel");
+}
+
+}  // namespace ld

@@ -38,7 +38,7 @@ def fly_population(drones: Sequence, timesteps: int = 2500, delta_t: float = 0.0
     start = np.array([[d.reward, d.coins, 2 * d.flight_time + int(d.crashed)] for d in drones], np.int32)
     import torch
     pop.istate.copy_(torch.from_numpy(start.T.copy()))
-    pop.fly(timesteps)
+    pop.fly(timesteps, engine="auto")
     res, state = pop.results(), pop.state_numpy()
     scores, times = [], []
     for i, d in enumerate(drones):

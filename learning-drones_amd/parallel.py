@@ -72,10 +72,10 @@ class ShardedPopulation:
         """rows_global: [n_total, P] on every rank (host array or tensor); each rank keeps its slice."""
         self.local.set_genomes(rows_global[self.begin:self.end])
 
-    def fly(self, timesteps: int):
+    def fly(self, timesteps: int, engine: str = "step"):
         """Rollout of the local shard, then the generation-end all-gather.  Returns the [n_total, 4]
         int32 record tensor (global drone order) on every rank."""
-        local = self.local.fly(timesteps)
+        local = self.local.fly(timesteps, engine=engine)
         return gather_records(local, self.n_total, self.group)
 
     @staticmethod
@@ -103,9 +103,10 @@ class DeviceEvolution:
     vector, so no index exchange is needed.  (An all-to-all of only the selected parents would move
     ~1/8 of that; at 8 x 446 MB the all-gather is ~10 ms against a 145 ms rollout.)"""
 
-    def __init__(self, population: "ShardedPopulation", ga=None, seed: int = 0):
+    def __init__(self, population: "ShardedPopulation", ga=None, seed: int = 0, engine: str = "auto"):
         from .params import GaParams
         self.pop = population
+        self.engine = engine
         self.ga = ga if ga is not None else GaParams.reference(seed=seed)
         self.generation = 0
         self.global_best_score = None
@@ -129,7 +130,7 @@ class DeviceEvolution:
         """One generation.  Returns (best_score, global_best_score, records)."""
         import torch
         pop = self.pop
-        records = pop.fly(timesteps)                                  # rollout + all-gather of records
+        records = pop.fly(timesteps, engine=self.engine)              # rollout + all-gather of records
         fitness = records[:, 0].contiguous()
         best_score = int(fitness.max().item())
         # FIRST maximum, as np.argmax (evolution.py:77); torch.argmax does not promise which of several

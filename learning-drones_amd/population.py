@@ -208,15 +208,33 @@ class Population:
         _native.check(rc, "ld_fly_finalize")
         self._finalized = True
 
-    def fly(self, timesteps: int = 2500):
-        """fly(drone, timesteps) for every drone: `timesteps` fused-step launches + finalize, enqueued
-        from C on the current stream.  Returns the device tensor of result records ([n, 4] int32
-        view of ld_fitness_record); see results()."""
+    RESIDENT_SPECS = ((10, 10), (16, 16), (32, 32), (64, 64, 64))
+
+    def fly(self, timesteps: int = 2500, engine: str = "step"):
+        """fly(drone, timesteps) for every drone, enqueued from C on the current stream.  Returns the
+        device tensor of result records ([n, 4] int32 view of ld_fitness_record); see results().
+
+        engine="step": `timesteps` launches of the fused step kernel (one launch advances the whole
+        population one timestep; genes streamed from HBM every step) + finalize.
+        engine="resident" (float32, specs RESIDENT_SPECS): one launch for the whole episode with the
+        genome held in registers (ld_fly_rollout_resident_f32); bit-identical results, 3-6x faster.
+        engine="auto": resident where available, else step."""
         if self._finalized:
             raise RuntimeError("episode already finalized; reset() first")
         args = [C.byref(self.sim), C.byref(self.episode), C.byref(self.spec), self._ptr(self.coins_dev),
                 self._ptr(self.walls_dev), self._ptr(self.genomes), self._ptr(self.fstate), self._ptr(self.istate),
                 self._ptr(self.records)]
+        if engine == "auto":
+            engine = "resident" if (self.precision == "f32" and self.spec.hidden_widths in self.RESIDENT_SPECS) else "step"
+        if engine == "resident":
+            if self.precision != "f32" or self.spec.hidden_widths not in self.RESIDENT_SPECS:
+                raise ValueError("the resident engine is float32 and covers the specs " + str(self.RESIDENT_SPECS))
+            args += [self.n, int(timesteps), self._stream()]
+            _native.check(_native.lib().ld_fly_rollout_resident_f32(*args), "ld_fly_rollout_resident_f32")
+            self._finalized = True
+            return self.records
+        if engine != "step":
+            raise ValueError("engine must be 'step' or 'resident'")
         if self.precision == "f64":
             args.append(self._ptr(self.distance))
         args += [self.n, int(timesteps), self._stream()]

@@ -415,3 +415,27 @@ def test_error_codes(Population):
     assert rc == -1
     rc = lib.ld_fly_step_f32(C.byref(pop.sim), C.byref(pop.episode), C.byref(spec), None, None, None, None, None, -1, None)
     assert rc == -3
+
+
+# ------------------------------------------------------------------------------------------- resident engine
+@pytest.mark.parametrize("hidden,n,T", [((32, 32), 1000, 600), ((16, 16), 1030, 2000), ((10, 10), 131, 2500),
+                                        ((64, 64, 64), 50, 300)])
+def test_resident_engine_is_bit_identical(Population, torch, hidden, n, T):
+    """The genome-resident whole-episode kernel (ld_fly_rollout_resident_f32) against the per-step
+    contract kernel: same arithmetic in the same order, so states, rewards, coins, flight times and
+    records must be equal bit for bit — for stable flyers, marginal and crashing genomes alike, with
+    population sizes that leave partial wavefronts."""
+    spec, genes, cls = _mixed_genomes(hidden, n, seed=n + 1)
+    walls = np.array([[3.0, 3.0, 8.0, 4.5, 7.0, 12.0]]) if hidden == (16, 16) else None
+    out = []
+    for engine in ("step", "resident"):
+        pop = Population(n, hidden, walls=walls)
+        pop.set_genomes(genes)
+        pop.fly(T, engine=engine)
+        out.append((pop.fstate.clone(), pop.istate.clone(), pop.records.clone()))
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
+    crashed = (out[0][1][2] & 1).bool()
+    assert crashed.any() and not crashed.all()
+    with pytest.raises(ValueError):
+        Population(4, (12,)).fly(10, engine="resident")       # no resident specialisation for this spec

@@ -212,7 +212,7 @@ def main():
         n_total = n_local * world
         value = n_total * T * args.steps / dt
         out = {
-            "metric": "drone-steps/sec (whole node), 65 536-drone population per GPU",
+            "metric": "drone-steps/sec (whole node) + generations/sec, 65 536-drone population",
             "value": value, "unit": "drone-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

@@ -439,3 +439,35 @@ def test_resident_engine_is_bit_identical(Population, torch, hidden, n, T):
     assert crashed.any() and not crashed.all()
     with pytest.raises(ValueError):
         Population(4, (12,)).fly(10, engine="resident")       # no resident specialisation for this spec
+
+
+def test_full_size_config5_shard(Population, torch):
+    """One GPU's share of BASELINE config 5: 131 072 drones x 4 000 steps, 15-64-64-64-4 controller
+    (5.0 GB of genes), 5-coin chain and wall boxes.  Size-independent properties: genomes replicated
+    from a 256-drone population under a random permutation give the permuted small-population
+    results bit for bit, and the resident engine equals the step engine at this size."""
+    hidden, n, T, m = (64, 64, 64), 131072, 4000, 256
+    spec, genes_m, _ = _mixed_genomes(hidden, m, seed=21)
+    coins = coin_chain_reference(5)
+    walls = np.array([[12.0, 3.0, 8.0, 13.0, 12.0, 12.0], [-20.0, -20.0, 30.0, 20.0, 20.0, 31.0]])
+    small = Population(m, hidden, coins=coins, walls=walls)
+    small.set_genomes(genes_m)
+    small.fly(T)
+    want = small.results()
+    g = torch.Generator(device=small.device).manual_seed(0)
+    src = torch.randint(0, m, (n,), generator=g, device=small.device)
+    rows = torch.as_tensor(genes_m, dtype=torch.float32, device=small.device).index_select(0, src)
+    results = []
+    for engine in ("step", "resident"):
+        pop = Population(n, hidden, coins=coins, walls=walls)
+        pop.set_genomes(rows)
+        pop.fly(T, engine=engine)
+        results.append((pop.results(), pop.fstate.clone(), pop.istate.clone()))
+        del pop
+    got = results[0][0]
+    idx = src.cpu().numpy()
+    for f in ("reward", "flight_time", "coins", "crashed", "distance_to_coin"):
+        assert np.array_equal(got[f], want[f][idx]), f
+    assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][2], results[1][2])
+    assert np.array_equal(results[0][0], results[1][0])
+    assert want["coins"].max() >= 1 and want["crashed"].any() and not want["crashed"].all()

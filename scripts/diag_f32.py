@@ -1,3 +1,6 @@
+"""Diagnostic: how float32 closed-loop trajectories of the GPU kernel, the float32 oracle and the
+float64 oracle diverge per genome class (chaos in tumbling drones); the numbers behind the L4 rung
+of tests/test_gpu_parity.py.  Run on a GPU box: python scripts/diag_f32.py"""
 import sys, numpy as np
 sys.path.insert(0, '.')
 sys.path.insert(0, 'tests')
@@ -7,12 +10,11 @@ from learning_drones_amd.params import *
 from oracle import oracle as O
 from test_gpu_parity import _mixed_genomes
 for hidden, n, T in (((16,16),1024,2000), ((32,32),1000,600)):
-    spec, genes = _mixed_genomes(hidden, n, seed=n)
+    spec, genes, cls = _mixed_genomes(hidden, n, seed=n)
     pop = Population(n, hidden, precision="f32"); pop.set_genomes(genes); pop.fly(T); got = pop.results()
     ref = O.fly(pop.sim, pop.episode, spec, genes, T, n_threads=O.max_threads(), mode=O.CLOSED_F32)
     ref64 = O.fly(pop.sim, pop.episode, spec, genes, T, n_threads=O.max_threads(), mode=O.FAITHFUL_F64)
-    hover = (np.arange(n) % 2 == 0)
-    for name, m in (("hover", hover), ("random", ~hover)):
+    for name, m in (("stable", cls == 0), ("marginal", cls == 1), ("random", cls == 2)):
         same = got["reward"][m] == ref.reward[m]
         same64 = got["reward"][m] == ref64.reward[m]
         cpu32_vs_64 = ref.reward[m] == ref64.reward[m]
@@ -34,4 +36,4 @@ for hidden, n, T in (((16,16),1024,2000), ((32,32),1000,600)):
         d = np.max(np.abs(s - tr.trace_state[t, :, :12]) / np.maximum(np.abs(tr.trace_state[t, :, :12]), 1e-2), axis=1)
         upd = (d > 1e-3) & (first == 400)
         first[upd] = t
-    print("first step with rel diff > 1e-3: hover", first[0::2][:16], "random", first[1::2][:16], "ft", tr.flight_time[1::2][:16])
+    print("first step with rel diff > 1e-3: stable", first[0::3][:10], "marginal", first[1::3][:10], "random", first[2::3][:10])

@@ -103,6 +103,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+        # bring the communicator up before anything is timed (also when --warmup 0)
+        dist.all_reduce(torch.zeros(1, device=device))
+        torch.cuda.synchronize()
 
     from learning_drones_amd.parallel import ShardedPopulation
     from learning_drones_amd.params import coin_chain_reference

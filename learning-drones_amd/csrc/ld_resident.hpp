@@ -36,8 +36,11 @@ template <int L, int... H> struct ResidentLayout {
     static constexpr int kGeneRegs = reg_offset(Shape::n_layers);
 };
 
+#ifndef LD_RES_WAVES
+#define LD_RES_WAVES 1
+#endif
 template <int L, int... H>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, LD_RES_WAVES)
 fly_resident_kernel(const ld_sim_params sim, const ld_episode_params ep, const double* __restrict__ coins,
                     const double* __restrict__ walls, const float* __restrict__ genomes, float* __restrict__ fstate,
                     int32_t* __restrict__ istate, const int64_t n, const int32_t timesteps)

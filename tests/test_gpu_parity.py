@@ -471,3 +471,30 @@ def test_full_size_config5_shard(Population, torch):
     assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][2], results[1][2])
     assert np.array_equal(results[0][0], results[1][0])
     assert want["coins"].max() >= 1 and want["crashed"].any() and not want["crashed"].all()
+
+
+def test_closed_loop_f32_stable_flyers_vs_reference(Population, g3):
+    """float32 production kernels against the reference's own closed-loop episodes of the stable
+    (coin-collecting hover) controllers: these flights are not chaotic, so float32 follows the
+    float64 reference for the whole 1 200-2 500 steps: same reward, coins and flight time, and the
+    final position within 1e-4 of the distance flown (north_star's rtol; measured: 7-9e-6 m on ~50 m)."""
+    seen = 0
+    for ei in range(int(g3["n_episodes"])):
+        if str(g3[f"kind_{ei}"]) != "hover":
+            continue
+        hidden = tuple(int(h) for h in g3[f"hidden_{ei}"])
+        T = int(g3[f"timesteps_{ei}"])
+        fin = g3[f"final_{ei}"]
+        for engine in ("step", "resident"):
+            pop = Population(1, hidden, precision="f32")
+            pop.set_genomes(g3[f"weights_{ei}"][None])
+            pop.fly(T, engine=engine)
+            r = pop.results()[0]
+            assert (r["coins"], r["flight_time"], bool(r["crashed"])) == (int(fin[2]), int(fin[3]), bool(fin[4]))
+            assert int(r["reward"]) == int(fin[0]), (ei, engine, int(r["reward"]), int(fin[0]))
+            pos = pop.position[:, 0].double().cpu().numpy()
+            ref = g3[f"state_{ei}"][-1, :3]
+            assert np.max(np.abs(pos - ref)) < RTOL_F32 * np.linalg.norm(ref - [0, 0, 10]), (ei, engine)
+            assert abs(r["distance_to_coin"] - fin[5]) < 1e-3
+        seen += 1
+    assert seen == 4

@@ -158,6 +158,36 @@ def main():
     bytes_per_launch = pop.local.bytes_per_drone_step * n_local
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
 
+    # Practical ceiling next to the spec peak: a device-to-device copy of 1 GiB on this
+    # GPU, read + write bytes over the event-timed duration.
+    src_buf = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=device).normal_()
+    dst_buf = torch.empty_like(src_buf)
+    for _ in range(3):
+        dst_buf.copy_(src_buf)
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c0.record()
+    for _ in range(10):
+        dst_buf.copy_(src_buf)
+    c1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 10 * 2 * src_buf.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+    del src_buf, dst_buf
+
+    # The reference's own kind of population (random genomes, evolve/brain.py:24): every drone tumbles
+    # and crashes within a few hundred steps; frozen wavefronts skip their gene traffic, so an episode
+    # costs far less than N*T full drone-steps.  Informational (live drone-steps only are real work).
+    pop.local.init_genomes_reference(seed=7 + rank)
+    random_pop = {}
+    for engine in ("step", "resident") if hidden in pop.local.RESIDENT_SPECS else ("step",):
+        pop.local.reset()
+        fence()
+        q0 = time.perf_counter()
+        rec = pop.fly(T, engine=engine)
+        fence()
+        random_pop[engine + "_episode_ms"] = (time.perf_counter() - q0) * 1e3
+    random_pop["live_drone_step_fraction"] = float(rec[:, 1].double().sum().item()) / (rec.shape[0] * T)
+    pop.local.set_genomes(make_genomes(torch, n_local, hidden, device, seed=rank))
+
     # HBM bytes per launch from the PMC counters: collected by separate rocprofv3 --pmc passes of this
     # same command and committed under profiles/ (they cannot be read live); used only when the
     # profiled launch configuration is the one being run.
@@ -227,6 +257,7 @@ def main():
             "evaluations_per_s": args.steps / dt,
             "live_drone_step_fraction": live,
             "resident_engine": resident,
+            "random_init_population": random_pop,
             "generations_per_s": n_gen / gen_dt,
             "generation": {"measured": n_gen, "includes": "rollout, record all-gather, elite, genome all-gather (N>1), "
                            "device select+breed (evolve/util.py + Drone.mutate semantics), reset; rollout engine: "
@@ -234,6 +265,7 @@ def main():
                            "live_drone_step_fraction": gen_live},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "copy_ceiling_gbs": copy_gbs,
                          "kernel": "fly_step_kernel<float, UnrolledNet<32,32>>" if hidden == (32, 32) else "fly_step_kernel",
                          "bytes_per_launch": bytes_per_launch, "launch_us": launch_ms * 1e3,
                          "bytes_per_drone_step": pop.local.bytes_per_drone_step},

@@ -3,10 +3,13 @@ evaluator behind the reference's Drone / fly() / evolve API (mbecker12/learning-
 
 Layout
   csrc/            HIP kernels + the C ABI of include/ld_drones.h  (libld_drones.so)
-  _native.py       ctypes binding of that ABI (fails loudly without the library or a GPU)
+  build.py         hipcc build of that library (parallel translation units)
+  _native.py       ctypes binding of the ABI (fails loudly without the library or a GPU)
   params.py        POD mirrors + the reference's constants
-  population.py    Population: SoA device state, genome packing, fly()
-  parallel.py      one-process-per-GPU sharding + fitness all-gather
+  population.py    Population: SoA device state, genome packing, fly(), breed(), checkpoints
+  parallel.py      one-process-per-GPU sharding, fitness all-gather, DeviceEvolution (GA loop on device)
+  pid.py           batched PID policy (BASELINE config 1 on the device)
+  controllers.py   hand-built hover controllers in the reference's weights format
   drone/ evolve/ flight/ objects/   drop-in mirrors of the reference's modules
 """
 from .params import (EpisodeParams, FitnessRecord, MlpSpec, SimParams, coin_chain_reference,  # noqa: F401

@@ -1,7 +1,7 @@
 // ld_device.hpp — device-side arithmetic of the fused drone step (gfx950 / CDNA4 only).
 //
 // One wavefront lane owns one drone.  Everything here is per-lane scalar code on values held
-// in VGPRs; the only memory traffic is in ld_kernels.hip.  Compile with -ffp-contract=off: the
+// in VGPRs; the only memory traffic is in ld_kernels.hpp / ld_nets.hpp.  Compile with -ffp-contract=off: the
 // places where a fused multiply-add is wanted say so with fma(), so that the float32 kernel
 // is the same arithmetic as the oracle's CLOSED_F32 mode and the float64 kernel can reproduce
 // the reference's rounding points.

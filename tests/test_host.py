@@ -116,3 +116,63 @@ def test_hover_net_is_exact_linear_feedback(oracle):
         v = np.c_[x, np.ones(16)] @ K.T
         want = 1 / (1 + np.exp(-0.4 * (z_h + (v @ pat) / slope)))
         assert np.allclose(y, want, rtol=0, atol=1e-12)
+
+
+def test_argument_validation_without_gpu(lib):
+    """Every entry point validates its arguments before it touches HIP, so the error behaviour of
+    the boundary can be checked on a CPU-only machine (no kernel is launched here: each call either
+    fails validation or is the n == 0 no-op)."""
+    from learning_drones_amd.params import GaParams
+    sim, ep, ga = SimParams.reference(), EpisodeParams.reference(n_coins=3), GaParams.reference()
+    spec, bad = MlpSpec.from_hidden((16, 16)), MlpSpec.from_hidden((16, 16))
+    bad.hidden[1] = 0
+    vp = C.c_void_p
+    fake = vp(0x1000)                      # non-null, 16-byte aligned, never dereferenced
+    odd = vp(0x1004)
+    OK, NULL, SPEC, SIZE, ALIGN = 0, -1, -2, -3, -4
+    for sfx in ("f32", "f64"):
+        step = getattr(lib, f"ld_fly_step_{sfx}")
+        assert step(None, C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, 8, None) == NULL
+        assert step(C.byref(sim), C.byref(ep), C.byref(bad), fake, None, fake, fake, fake, 8, None) == SPEC
+        assert step(C.byref(sim), None, C.byref(spec), fake, None, fake, fake, fake, 8, None) == NULL
+        assert step(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, -1, None) == SIZE
+        assert step(C.byref(sim), C.byref(ep), C.byref(spec), None, None, None, None, None, 0, None) == OK      # empty population
+        assert step(C.byref(sim), C.byref(ep), C.byref(spec), None, None, fake, fake, fake, 8, None) == NULL    # no coin table
+        assert step(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, odd, fake, fake, 8, None) == ALIGN
+        many = EpisodeParams.reference(n_coins=65)
+        assert step(C.byref(sim), C.byref(many), C.byref(spec), fake, None, fake, fake, fake, 8, None) == SIZE
+        walled = EpisodeParams.reference(n_coins=3, n_walls=2)
+        assert step(C.byref(sim), C.byref(walled), C.byref(spec), fake, None, fake, fake, fake, 8, None) == NULL  # walls missing
+        roll = getattr(lib, f"ld_fly_rollout_{sfx}")
+        args = [C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, fake]
+        args += [fake] if sfx == "f64" else []
+        assert roll(*args, 8, -5, None) == SIZE
+        assert getattr(lib, f"ld_measure_{sfx}")(C.byref(sim), C.byref(ep), None, None, 0, None) == OK
+        assert getattr(lib, f"ld_measure_{sfx}")(C.byref(sim), C.byref(ep), None, None, 4, None) == NULL
+        assert getattr(lib, f"ld_mlp_forward_{sfx}")(C.byref(bad), fake, fake, fake, 4, None) == SPEC
+        assert getattr(lib, f"ld_mlp_forward_{sfx}")(C.byref(spec), odd, fake, fake, 4, None) == ALIGN
+        assert getattr(lib, f"ld_population_reset_{sfx}")(None, None, 0, None, None) == OK
+        assert getattr(lib, f"ld_population_reset_{sfx}")(None, None, 3, None, None) == NULL
+        assert getattr(lib, f"ld_genomes_pack_{sfx}")(fake, 10, fake, 4, 20, None) == SIZE                       # row stride < P
+        assert getattr(lib, f"ld_genomes_unpack_{sfx}")(odd, fake, 20, 4, 20, None) == ALIGN
+        breed = getattr(lib, f"ld_ga_breed_{sfx}")
+        assert breed(C.byref(ga), C.byref(spec), fake, 8, 1, fake, fake, None, 0, 7, vp(0x2000), None) == SIZE   # odd children
+        assert breed(C.byref(ga), C.byref(spec), fake, 8, 1, fake, fake, None, 0, 8, fake, None) == SIZE         # dst aliases src
+        assert breed(C.byref(ga), C.byref(spec), fake, 8, 1, fake, fake, None, 0, 0, fake, None) == OK
+        assert breed(None, C.byref(spec), fake, 8, 1, fake, fake, None, 0, 8, vp(0x2000), None) == NULL
+        pid = getattr(lib, f"ld_pid_episode_{sfx}")
+        assert pid(C.byref(sim), fake, fake, 0, 1.0, 1000, 100, fake, fake, fake, fake, None, 4, None) == SIZE   # no coins
+        assert pid(C.byref(sim), None, None, 4, 1.0, 1000, 100, None, None, None, None, None, 0, None) == OK
+        assert pid(C.byref(sim), None, fake, 4, 1.0, 1000, 100, fake, fake, fake, fake, None, 4, None) == NULL
+    assert lib.ld_ga_select(C.byref(ga), C.byref(spec), fake, 7, 0, 6, fake, fake, None) == SIZE                # odd population
+    assert lib.ld_ga_select(C.byref(ga), C.byref(spec), fake, 8, 4, 6, fake, fake, None) == SIZE                # children overrun
+    assert lib.ld_ga_select(C.byref(ga), C.byref(spec), fake, 8, 0, 0, None, None, None) == OK
+    assert lib.ld_ga_select(C.byref(ga), C.byref(spec), None, 8, 0, 8, fake, fake, None) == NULL
+    res = lib.ld_fly_rollout_resident_f32
+    unsupported = MlpSpec.from_hidden((12,))
+    assert res(C.byref(sim), C.byref(ep), C.byref(unsupported), fake, None, fake, fake, fake, fake, 8, 10, None) == SPEC
+    assert res(C.byref(sim), C.byref(ep), C.byref(spec), None, None, None, None, None, None, 0, 10, None) == OK
+    assert lib.ld_genome_words(C.byref(spec), 65) == 2 * 64 * 149 and lib.ld_genome_words(C.byref(spec), 0) == 0
+    assert lib.ld_genome_words(C.byref(spec), -1) == SIZE
+    for code in (0, -1, -2, -3, -4, -5, -6, -99):
+        assert lib.ld_strerror(code)

@@ -52,6 +52,59 @@ def gather_records(local_records, n_total: int, process_group=None):
     return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
 
 
+class DistComm:
+    """Variable-size all-to-all over a torch.distributed group (RCCL on GPUs, gloo in CPU tests)."""
+
+    def __init__(self, group):
+        import torch.distributed as dist
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def all_to_all(self, send):
+        """send[r]: tensor for rank r (first dimension may differ per destination, trailing dimensions
+        equal).  Returns recv with recv[r] = what rank r sent here."""
+        import torch
+        import torch.distributed as dist
+        dev = send[0].device
+        counts = torch.tensor([t.shape[0] for t in send], dtype=torch.int64, device=dev)
+        incoming = torch.empty_like(counts)
+        dist.all_to_all_single(incoming, counts, group=self.group)
+        incoming = [int(c) for c in incoming.tolist()]
+        out = torch.empty((sum(incoming),) + tuple(send[0].shape[1:]), dtype=send[0].dtype, device=dev)
+        dist.all_to_all_single(out, torch.cat(send).contiguous(), output_split_sizes=incoming,
+                               input_split_sizes=[t.shape[0] for t in send], group=self.group)
+        return list(out.split(incoming))
+
+
+def exchange_parent_genomes(genomes_local, n_local: int, parents_global, comm):
+    """Fetch exactly the parent genomes this rank's children need (selection draws parents
+    uniformly over the whole population, so ~(W-1)/W of them live on other ranks).
+
+    genomes_local: this rank's genome array [blocks, W, 64, 4]; parents_global: int tensor of global
+    drone indices (one per local child); every rank owns n_local consecutive drones.  Two all-to-alls:
+    the requested indices, then the genome rows.  Returns (compact, parents_compact): a genome array
+    holding only the distinct needed parents, and the parents re-indexed into it — exactly what
+    ld_ga_breed takes as src / parents with one segment."""
+    import torch
+    from .params import GENOME_BLOCK
+    needed = torch.unique(parents_global.long())                          # sorted, distinct
+    owner = torch.div(needed, n_local, rounding_mode="floor")
+    requests = [needed[owner == r] for r in range(comm.world)]            # sorted by owner already
+    to_serve = comm.all_to_all(requests)                                  # indices other ranks want from me
+    rows_out = []
+    for idx in to_serve:
+        slot = idx - comm.rank * n_local
+        rows_out.append(genomes_local[torch.div(slot, GENOME_BLOCK, rounding_mode="floor"), :, slot % GENOME_BLOCK, :])
+    rows = torch.cat(comm.all_to_all(rows_out))                           # [len(needed), W, 4], in `needed` order
+    W = genomes_local.shape[1]
+    blocks = (needed.numel() + GENOME_BLOCK - 1) // GENOME_BLOCK
+    padded = torch.zeros((blocks * GENOME_BLOCK, W, 4), dtype=genomes_local.dtype, device=genomes_local.device)
+    padded[: needed.numel()] = rows
+    compact = padded.view(blocks, GENOME_BLOCK, W, 4).permute(0, 2, 1, 3).contiguous()
+    parents_compact = torch.searchsorted(needed, parents_global.long()).to(torch.int32)
+    return compact, parents_compact
+
+
 class ShardedPopulation:
     """A population of n_total drones split over the ranks of `process_group`; `local` is this
     rank's Population shard (learning-drones_amd/population.py)."""
@@ -97,16 +150,22 @@ class DeviceEvolution:
     mutation + elitism (Population.breed), state reset.  One instance per rank.
 
     Multi-GPU: tournament selection draws parents uniformly over the WHOLE population
-    (evolve/util.py:9-14), so children on rank r need genomes that live on other ranks.  Each
-    generation the ranks all-gather their genome shards (cfg3: 446 MB per rank) and breed from the
-    gathered copy; every rank runs the same Philox-keyed selection on the same gathered fitness
-    vector, so no index exchange is needed.  (An all-to-all of only the selected parents would move
-    ~1/8 of that; at 8 x 446 MB the all-gather is ~10 ms against a 145 ms rollout.)"""
+    (evolve/util.py:9-14), so children on rank r need genomes that live on other ranks.  Every rank
+    runs the same Philox-keyed selection for its own children on the same gathered fitness vector and
+    then fetches exactly the distinct parents it needs with two all-to-alls (exchange="alltoall":
+    requested indices, then genome rows; about one shard's worth of genes in and out per rank, 1/W of
+    an all-gather).  exchange="allgather" is the simple variant: all-gather every shard (cfg3: 446 MB
+    per rank) and breed from the gathered copy."""
 
-    def __init__(self, population: "ShardedPopulation", ga=None, seed: int = 0, engine: str = "auto"):
+    def __init__(self, population: "ShardedPopulation", ga=None, seed: int = 0, engine: str = "auto",
+                 exchange: str = "alltoall"):
         from .params import GaParams
+        if exchange not in ("alltoall", "allgather"):
+            raise ValueError("exchange must be 'alltoall' or 'allgather'")
         self.pop = population
         self.engine = engine
+        self.exchange = exchange
+        self._alltoall_checked = False
         self.ga = ga if ga is not None else GaParams.reference(seed=seed)
         self.generation = 0
         self.global_best_score = None
@@ -114,13 +173,12 @@ class DeviceEvolution:
         self.history = []
 
     def _gather_genomes(self):
+        """All-gather variant of the parent exchange: every rank receives every shard."""
         import torch
         import torch.distributed as dist
         local = self.pop.local.genomes
         if self.pop.world == 1:
             return local, self.pop.local.n, 1
-        if self.pop.n_total % self.pop.world:
-            raise ValueError("the device generation step needs equal shards (n_total divisible by the world size)")
         out = torch.empty((self.pop.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
                           device=local.device)      # shards back to back = the segments of ld_ga_breed
         dist.all_gather_into_tensor(out, local.contiguous(), group=self.pop.group)
@@ -147,10 +205,29 @@ class DeviceEvolution:
                 import torch.distributed as dist
                 dist.broadcast(elite, src=dist.get_global_rank(pop.group, owner), group=pop.group)
             self.elite = elite
-        src, n_per_segment, n_segments = self._gather_genomes()
         self.ga.generation = self.generation
-        pop.local.breed(fitness, self.ga, elite=self.elite, child_begin=pop.begin, src=src,
-                        n_per_segment=n_per_segment, n_segments=n_segments)
+        if pop.world > 1 and pop.n_total % pop.world:
+            raise ValueError("the device generation step needs equal shards (n_total divisible by the world size)")
+        if pop.world > 1 and self.exchange == "alltoall" and not self._alltoall_checked:
+            # a backend without all-to-all on device tensors (gloo) raises on every rank alike at the
+            # first call; all ranks then take the all-gather variant together
+            try:
+                DistComm(pop.group).all_to_all([torch.zeros((1,), dtype=torch.int64, device=pop.local.device)
+                                                for _ in range(pop.world)])
+            except RuntimeError as err:
+                self.exchange = "allgather"
+                if pop.rank == 0:
+                    print(f"[learning-drones_amd] all-to-all unavailable on this backend ({err}); using all-gather")
+            self._alltoall_checked = True
+        if pop.world > 1 and self.exchange == "alltoall":
+            # only the selected parents travel (~1/W of an all-gather)
+            pop.local.breed(fitness, self.ga, elite=self.elite, child_begin=pop.begin,
+                            fetch_parents=lambda parents: exchange_parent_genomes(pop.local.genomes, pop.local.n, parents,
+                                                                                  DistComm(pop.group)))
+        else:
+            src, n_per_segment, n_segments = self._gather_genomes()
+            pop.local.breed(fitness, self.ga, elite=self.elite, child_begin=pop.begin, src=src,
+                            n_per_segment=n_per_segment, n_segments=n_segments)
         pop.local.reset()                                             # Drone.reset for every child
         self.generation += 1
         self.history.append((best_score, self.global_best_score))

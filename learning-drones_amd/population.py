@@ -260,7 +260,7 @@ class Population:
         return self.genomes[slot // GENOME_BLOCK, :, slot % GENOME_BLOCK, :].contiguous()
 
     def breed(self, fitness_all, ga: GaParams, *, elite=None, child_begin: int = 0, src=None,
-              n_per_segment: Optional[int] = None, n_segments: int = 1) -> None:
+              n_per_segment: Optional[int] = None, n_segments: int = 1, fetch_parents=None) -> None:
         """Replace this population's genomes by the next generation (evolve/util.py:5-78 +
         drone/drone.py:167-172 + the elitism of evolve/evolution.py:105-107), on the device.
 
@@ -268,7 +268,8 @@ class Population:
         children are global slots [child_begin, child_begin + n)); src: the genome words the parents
         are read from — n_segments back-to-back arrays of n_per_segment drones (default: this
         population's own genomes, one segment); elite: W x 4 genome words copied unmutated into
-        global child 0, or None."""
+        global child 0, or None; fetch_parents: optional callable(parents_global) -> (src genome array,
+        parents re-indexed into it) used by the multi-GPU all-to-all exchange (parallel.py)."""
         torch = _torch()
         if self.n % 2:
             raise ValueError("the generation step pairs slots (i, i+1): the shard size must be even")
@@ -282,6 +283,11 @@ class Population:
         lib = _native.lib()
         _native.check(lib.ld_ga_select(C.byref(ga), C.byref(self.spec), self._ptr(fitness_all), n_total, child_begin,
                                        self.n, self._ptr(parents), self._ptr(cuts), self._stream()), "ld_ga_select")
+        self.last_parents = parents
+        if fetch_parents is not None:
+            src, parents = fetch_parents(parents)
+            src, parents = src.contiguous(), parents.to(device=self.device, dtype=torch.int32).contiguous()
+            n_per_segment, n_segments = src.shape[0] * GENOME_BLOCK, 1
         children = torch.empty_like(self.genomes)
         if elite is not None:
             elite = elite.to(device=self.device, dtype=self.dtype).contiguous()
@@ -289,7 +295,7 @@ class Population:
                                               self._ptr(parents), self._ptr(cuts), self._ptr(elite), child_begin, self.n,
                                               self._ptr(children), self._stream()), "ld_ga_breed")
         self.genomes = children
-        self.last_parents, self.last_cuts = parents, cuts
+        self.last_cuts = cuts
 
     # ------------------------------------------------------------------ checkpoint / replay
     def state_dict(self) -> dict:

@@ -286,3 +286,66 @@ def test_pid_policy_matches_reference_episodes(g4):
     k = names.index("11")
     assert np.max(np.abs(f32["trace"][:300, k, :3] - g4["state_11"][:300, :3])) < 1e-2
     assert np.array_equal(f32["coins"], out["coins"])
+
+
+def test_alltoall_parent_exchange_equals_allgather():
+    """Multi-GPU generation step, both exchange variants, simulated on one GPU with one thread per
+    virtual rank and a mailbox standing in for the collective: breeding from the fetched distinct
+    parents (all-to-all) must give exactly the children that breeding from the all-gathered shards
+    gives, and those must equal the single-population result."""
+    import threading
+    import torch
+    from learning_drones_amd.parallel import exchange_parent_genomes
+    from learning_drones_amd.params import GaParams
+    from learning_drones_amd.population import Population
+    n, hidden, world = 768, (16, 16), 4
+    n_local = n // world
+    rng = np.random.default_rng(0)
+    genes = rng.normal(0, 1, (n, 596)).astype(np.float32)
+    fitness = torch.as_tensor(rng.integers(-4000, 4000, n).astype(np.int32))
+    ga = GaParams.reference(seed=9, generation=5, p_crossover=0.5)
+    whole = Population(n, hidden)
+    whole.set_genomes(genes)
+    elite = whole.genome_of(3)
+    whole.breed(fitness, ga, elite=elite)
+    want = whole.get_genomes().cpu().numpy()
+
+    shards = []
+    for r in range(world):
+        p = Population(n_local, hidden)
+        p.set_genomes(genes[r * n_local:(r + 1) * n_local])
+        shards.append(p)
+    original = [p.genomes.clone() for p in shards]
+
+    class ThreadComm:
+        box, barrier = {}, threading.Barrier(world)
+
+        def __init__(self, rank):
+            self.rank, self.world = rank, world
+
+        def all_to_all(self, send):
+            ThreadComm.box[self.rank] = send
+            ThreadComm.barrier.wait()
+            recv = [ThreadComm.box[r][self.rank] for r in range(world)]
+            ThreadComm.barrier.wait()
+            return recv
+
+    errors = []
+
+    def run(r):
+        try:
+            torch.cuda.set_device(0)
+            shards[r].breed(fitness, ga, elite=elite, child_begin=r * n_local,
+                            fetch_parents=lambda parents: exchange_parent_genomes(original[r], n_local, parents, ThreadComm(r)))
+        except Exception as e:                                         # surfaced below
+            errors.append(e)
+            ThreadComm.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    got = np.concatenate([p.get_genomes().cpu().numpy() for p in shards])
+    assert np.array_equal(got, want)

@@ -68,3 +68,50 @@ def test_gather_records_world2(n_total):
     for rank, full, winners in out:
         assert np.array_equal(full, want)
     assert np.array_equal(out[0][2], out[1][2])
+
+
+def _exchange_worker(rank, world, port, q):
+    sys.path.insert(0, str(REPO))
+    import torch
+    import torch.distributed as dist
+    from learning_drones_amd.parallel import DistComm, exchange_parent_genomes
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_local, W = 96, 5                                    # 1.5 genome blocks per rank
+        gen = torch.Generator().manual_seed(0)
+        whole = torch.randn((world * n_local, W, 4), generator=gen)                      # every rank builds the same
+        mine = whole[rank * n_local:(rank + 1) * n_local]
+        blocks = (n_local + 63) // 64
+        pad = torch.zeros((blocks * 64, W, 4))
+        pad[:n_local] = mine
+        genomes_local = pad.view(blocks, 64, W, 4).permute(0, 2, 1, 3).contiguous()      # the blocked layout
+        pg = torch.Generator().manual_seed(100 + rank)
+        parents = torch.randint(0, world * n_local, (n_local,), generator=pg, dtype=torch.int32)
+        compact, idx = exchange_parent_genomes(genomes_local, n_local, parents, DistComm(dist.group.WORLD))
+        rows = compact.permute(0, 2, 1, 3).reshape(-1, W, 4)                              # back to one row per slot
+        q.put((rank, torch.equal(rows[idx.long()], whole[parents.long()]), int(torch.unique(parents).numel()),
+               tuple(compact.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_parent_exchange_world2():
+    """The all-to-all parent exchange of the multi-GPU generation step on CPU tensors: every child gets
+    exactly its parent's genome, and only the distinct needed parents are materialised."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, n_unique, shape in out:
+        assert same
+        assert shape == ((n_unique + 63) // 64, 5, 64, 4)

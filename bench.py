@@ -233,20 +233,23 @@ def main():
     # 1 / episode time; the live fraction of the measured generations is reported next to it.
     from learning_drones_amd.parallel import DeviceEvolution
     evo = DeviceEvolution(pop, seed=0x1D20)
-    pop.local.reset()
-    evo.step(T)
-    fence()
-    g0 = time.perf_counter()
-    n_gen, gen_live = 3, 0.0
-    for _ in range(n_gen):
-        _, _, rec = evo.step(T)
-        gen_live += float(rec[:, 1].double().sum().item()) / (rec.shape[0] * T) / n_gen
-    fence()
-    gen_dt = time.perf_counter() - g0
-    if dist:
-        tmax = torch.tensor([gen_dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        gen_dt = float(tmax.item())
+    n_gen, gen_live, gen_dt, gen_error = 3, 0.0, float("nan"), None
+    try:
+        pop.local.reset()
+        evo.step(T)
+        fence()
+        g0 = time.perf_counter()
+        for _ in range(n_gen):
+            _, _, rec = evo.step(T)
+            gen_live += float(rec[:, 1].double().sum().item()) / (rec.shape[0] * T) / n_gen
+        fence()
+        gen_dt = time.perf_counter() - g0
+        if dist:
+            tmax = torch.tensor([gen_dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            gen_dt = float(tmax.item())
+    except RuntimeError as err:          # e.g. a backend without the collectives the generation step uses
+        gen_error = str(err)[:200]
 
     if rank == 0:
         n_total = n_local * world
@@ -265,11 +268,11 @@ def main():
             "live_drone_step_fraction": live,
             "resident_engine": resident,
             "random_init_population": random_pop,
-            "generations_per_s": n_gen / gen_dt,
+            "generations_per_s": None if gen_error else n_gen / gen_dt,
             "generation": {"measured": n_gen, "includes": "rollout, record all-gather, elite, genome all-gather (N>1), "
                            "device select+breed (evolve/util.py + Drone.mutate semantics), reset; rollout engine: "
-                           + evo.engine,
-                           "live_drone_step_fraction": gen_live},
+                           + evo.engine + ", parent exchange: " + (evo.exchange if world > 1 else "local"),
+                           "live_drone_step_fraction": gen_live, "error": gen_error},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "copy_ceiling_gbs": copy_gbs,

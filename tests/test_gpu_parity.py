@@ -371,19 +371,25 @@ def test_full_size_properties(Population, torch):
     assert want["coins"].max() == 3 and want["crashed"].any() and not want["crashed"].all()
 
 
-def test_edge_sizes(Population):
-    """Empty population, a single drone, and sizes around the wavefront width."""
+@pytest.mark.parametrize("engine", ["step", "resident"])
+def test_edge_sizes(Population, engine):
+    """Empty population, a single drone, sizes around the wavefront width (and around the resident
+    engine's 8 drones per wavefront), and a zero-step episode."""
     pop = Population(0, (16, 16))
-    pop.fly(10)
+    pop.fly(10, engine=engine)
     assert len(pop.results()) == 0
     ref = None
-    for n in (1, 63, 64, 65, 129):
+    for n in (1, 7, 8, 9, 63, 64, 65, 129):
         p = Population(n, (16, 16))
-        p.fly(200)                                   # zero genomes: thrust 0.5 each, everyone climbs
+        p.fly(200, engine=engine)                    # zero genomes: thrust 0.5 each, everyone climbs
         r = p.results()
         assert (r == r[0]).all()
         ref = r[0] if ref is None else ref
         assert r[0] == ref
+    z = Population(5, (16, 16))
+    z.fly(0, engine=engine)                          # no step: only the distance penalty to coin 0
+    r = z.results()
+    assert (r["flight_time"] == 0).all() and (r["reward"] == -100 * int(np.sqrt(50.0))).all()
 
 
 def test_frozen_after_crash_and_idempotent_guard(Population, torch):

@@ -36,6 +36,11 @@ template <int L, int... H> struct ResidentLayout {
     static constexpr int kGeneRegs = reg_offset(Shape::n_layers);
 };
 
+// A workgroup is one wavefront, and a wavefront's LDS operations execute in issue order, so the
+// exchange needs no hardware barrier: only the compiler must not move LDS accesses across it.
+#ifndef LD_RES_SYNC
+#define LD_RES_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
 #ifndef LD_RES_WAVES
 #define LD_RES_WAVES 1
 #endif
@@ -107,24 +112,34 @@ fly_resident_kernel(const ld_sim_params sim, const ld_episode_params ep, const d
             constexpr int layer = decltype(lc)::value;
             constexpr int n_in = Shape::dims[layer], n_out = Shape::dims[layer + 1];
             constexpr bool last = layer == Shape::n_layers - 1;
-            static_for<0, Lay::slots(layer)>([&](auto qc) __attribute__((always_inline)) {
+            // the lane's neurons advance together, input by input: Q independent fma chains in flight
+            // (each neuron's own sum still runs in gene order, so the result is unchanged)
+            constexpr int Q = Lay::slots(layer);
+            constexpr int stride = n_in + 1;
+            float acc[Q];
+            static_for<0, Q>([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value;
-                constexpr int base = Lay::reg_offset(layer) + q * (n_in + 1);
-                float acc = mac<float, true>(genes[base], act[0], 0.0f);
-                static_for<1, n_in>([&](auto kc) __attribute__((always_inline)) {
-                    constexpr int k = decltype(kc)::value;
-                    acc = mac<float, true>(genes[base + k], act[k], acc);
+                acc[q] = mac<float, true>(genes[Lay::reg_offset(layer) + q * stride], act[0], 0.0f);
+            });
+            static_for<1, n_in>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                static_for<0, Q>([&](auto qc) __attribute__((always_inline)) {
+                    constexpr int q = decltype(qc)::value;
+                    acc[q] = mac<float, true>(genes[Lay::reg_offset(layer) + q * stride + k], act[k], acc[q]);
                 });
-                acc = acc + genes[base + n_in];
-                const float y = last ? sigmoid04<float>(acc) : relu<float>(acc);
+            });
+            static_for<0, Q>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int q = decltype(qc)::value;
+                const float sum = acc[q] + genes[Lay::reg_offset(layer) + q * stride + n_in];
+                const float y = last ? sigmoid04<float>(sum) : relu<float>(sum);
                 const int j = l + q * L;
                 if (j < n_out) xch[layer & 1][g][j] = y;
             });
-            __syncthreads();                               // one wavefront per workgroup: orders LDS write -> read
+            LD_RES_SYNC();                                 // one wavefront per workgroup: orders LDS write -> read
 #pragma unroll
             for (int k = 0; k < n_out; ++k) act[k] = xch[layer & 1][g][k];
         });
-        __syncthreads();                                   // the next step's first layer reuses buffer 0
+        LD_RES_SYNC();                                     // the next step's first layer reuses buffer 0
 
         if (!dead) {                                       // commit, as fly_step_kernel does
 #pragma unroll

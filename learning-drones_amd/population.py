@@ -322,23 +322,38 @@ class Population:
         pop._finalized = bool(z["finalized"])
         return pop
 
-    def record_trajectory(self, timesteps: int, slots: Sequence[int] = (0,)) -> np.ndarray:
+    RESULTS_CSV_HEADER = ("Time, Roll, Pitch, Yaw, X, Y, Z, T1, T2, T3, T4, Wind X, Wind Y, PID Roll, PID Pitch, PID Yaw, "
+                          "PID X, PID Y, PID Z, Set Roll, Set Pitch, Set Yaw, Set X, Set Y, Set Z")
+
+    def record_trajectory(self, timesteps: int, slots: Sequence[int] = (0,), csv_prefix: Optional[str] = None) -> np.ndarray:
         """Fly `timesteps` steps (from the current state) and return the per-step log of the chosen
-        drones in the column order of the reference's Results.csv (datahandling/data_scraper.py:
-        300-307): time [s], roll, pitch, yaw [deg], x, y, z [m], thrust 1-4.  Shape
-        [len(slots), timesteps, 11]; rows after a crash repeat the frozen state."""
+        drones in the 25-column layout of the reference's Results.csv (datahandling/data_scraper.py:
+        285-307): time [s]; roll, pitch, yaw [deg]; x, y, z [m]; thrust 1-4; wind x, y; six PID columns
+        (zero: the controller here is the network); set-points roll, pitch, yaw (zero) and x, y, z (the
+        coin the drone is flying to).  Shape [len(slots), timesteps, 25]; rows after a crash repeat the
+        frozen state.  With csv_prefix, also writes <csv_prefix><slot>.csv with the reference's header,
+        which the reference's own viewers / plot scripts read."""
         torch = _torch()
         idx = torch.as_tensor(list(slots), device=self.device, dtype=torch.long)
-        log = torch.empty((int(timesteps), F_COUNT, len(idx)), dtype=self.dtype, device=self.device)
-        for t in range(int(timesteps)):
+        T = int(timesteps)
+        log = torch.empty((T, F_COUNT, len(idx)), dtype=self.dtype, device=self.device)
+        coin = torch.empty((T, len(idx)), dtype=torch.int32, device=self.device)
+        for t in range(T):
             self.step()
             log[t] = self.fstate.index_select(1, idx)
+            coin[t] = self.istate[I_COINS].index_select(0, idx)
         a = log.permute(2, 0, 1).double().cpu().numpy()
-        out = np.empty((len(idx), int(timesteps), 11))
-        out[:, :, 0] = np.arange(int(timesteps))[None, :] * float(self.sim.dt)
+        target = self.coins_host[np.minimum(coin.t().cpu().numpy(), len(self.coins_host) - 1)][:, :, :3]
+        out = np.zeros((len(idx), T, 25))
+        out[:, :, 0] = np.arange(T)[None, :] * float(self.sim.dt)
         out[:, :, 1:4] = np.degrees(a[:, :, F_ANGLE:F_ANGLE + 3])
         out[:, :, 4:7] = a[:, :, F_POS:F_POS + 3]
         out[:, :, 7:11] = a[:, :, F_THRUST:F_THRUST + 4]
+        out[:, :, 11], out[:, :, 12] = float(self.sim.wind[0]), float(self.sim.wind[1])
+        out[:, :, 22:25] = target
+        if csv_prefix is not None:
+            for k, slot in enumerate(slots):
+                np.savetxt(f"{csv_prefix}{slot}.csv", out[k], delimiter=",", header=self.RESULTS_CSV_HEADER)
         return out
 
     # ------------------------------------------------------------------ accounting

@@ -252,10 +252,15 @@ def test_checkpoint_resume_and_replay(tmp_path):
         p.step()
     p.save(str(tmp_path / "pop.npz"))
     q = Population.load(str(tmp_path / "pop.npz"))
-    log_p, log_q = p.record_trajectory(100, slots=(0, 5)), q.record_trajectory(100, slots=(0, 5))
-    assert np.array_equal(log_p, log_q) and log_p.shape == (2, 100, 11)
+    log_p = p.record_trajectory(100, slots=(0, 5), csv_prefix=str(tmp_path / "drone_"))
+    log_q = q.record_trajectory(100, slots=(0, 5))
+    assert np.array_equal(log_p, log_q) and log_p.shape == (2, 100, 25)
     assert np.allclose(log_p[0, :, 0], np.arange(100) * 0.01)
     assert np.allclose(log_p[1, -1, 4:7], p.position[:, 5].double().cpu().numpy())
+    assert np.array_equal(log_p[0, 0, 22:25], [5.0, 5.0, 10.0])                 # flying to the first coin
+    text = (tmp_path / "drone_5.csv").read_text().splitlines()
+    assert text[0] == "# " + Population.RESULTS_CSV_HEADER and len(text) == 101   # the reference's Results.csv header
+    assert np.allclose(np.loadtxt(tmp_path / "drone_5.csv", delimiter=","), log_p[1])
     assert torch.equal(p.fstate, q.fstate) and torch.equal(p.istate, q.istate)
 
 

@@ -55,3 +55,8 @@ def g5():
 @pytest.fixture(scope="session")
 def g6():
     return load_golden("g6_ga.npz")
+
+
+@pytest.fixture(scope="session")
+def g7():
+    return load_golden("g7_flags.npz")

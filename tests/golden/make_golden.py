@@ -25,6 +25,7 @@ row-major ``(n_out, n_in + 1)`` matrix, layers concatenated):
                    reference's own PID / physics / Sensor / Coin classes)
   g5_events.npz    reward-event KATs: tiny ``fly()`` episodes straddling thresholds
   g6_ga.npz        GA operator KATs under ``np.random.seed``
+  g7_flags.npz     ``fly()`` keyword variants: punish_time / reward_time / delta_t / timesteps
 """
 import os
 import subprocess
@@ -39,7 +40,7 @@ if os.environ.get("LD_GOLDEN_CHILD") != "1":
     scratch = Path("/tmp/ld_golden_scratch")
     scratch.mkdir(parents=True, exist_ok=True)
     env = dict(os.environ, LD_GOLDEN_CHILD="1", PYTHONPATH=REF, PYTHONDONTWRITEBYTECODE="1")
-    sys.exit(subprocess.call([sys.executable, str(Path(__file__).resolve())], cwd=scratch, env=env))
+    sys.exit(subprocess.call([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], cwd=scratch, env=env))
 
 import contextlib
 import importlib.util
@@ -420,12 +421,37 @@ def make_g6():
     np.savez_compressed(HERE / "g6_ga.npz", **out)
 
 
+# --------------------------------------------------------------------------- G7
+def make_g7():
+    """fly() keyword variants (flight/__init__.py:12-21, 40-45): punish_time / reward_time switch the
+    +-2 airtime term, delta_t only scales the returned time, timesteps bounds the loop."""
+    cases = []
+    for seed, kw in ((60, dict(punish_time=True, reward_time=False)), (61, dict(punish_time=True, reward_time=True)),
+                     (62, dict(punish_time=False, reward_time=False)), (63, dict(delta_t=0.05)),
+                     (64, dict(timesteps=120)), (65, dict(timesteps=120, punish_time=True, reward_time=False, delta_t=0.2))):
+        np.random.seed(seed)
+        d = new_drone()
+        weights = flat(d.controller.weights)
+        args = dict(timesteps=2500, delta_t=0.01, punish_time=False, reward_time=True)
+        args.update(kw)
+        reward, real_time, idx = fly(d, idx=3, **args)
+        cases.append((weights, [args["timesteps"], args["delta_t"], int(args["punish_time"]), int(args["reward_time"])],
+                      [reward, real_time, d.coins, d.flight_time, int(d.crashed), d.distance_to_coin]))
+        print("g7", seed, kw, cases[-1][2])
+    np.savez_compressed(HERE / "g7_flags.npz", weights=np.stack([c[0] for c in cases]),
+                        args=np.array([c[1] for c in cases], float), final=np.array([c[2] for c in cases], float))
+
+
 if __name__ == "__main__":
+    if "--only-g7" in sys.argv:
+        make_g7()
+        sys.exit(0)
     make_g1()
     make_g2()
     make_g3()
     make_g4()
     make_g5()
     make_g6()
+    make_g7()
     sizes = {p.name: p.stat().st_size for p in sorted(HERE.glob("*.npz"))}
     print("written:", sizes, "total", sum(sizes.values()))

@@ -354,3 +354,22 @@ def test_alltoall_parent_exchange_equals_allgather():
     assert not errors, errors
     got = np.concatenate([p.get_genomes().cpu().numpy() for p in shards])
     assert np.array_equal(got, want)
+
+
+def test_fly_keyword_variants(g7):
+    """fly(drone, timesteps=, delta_t=, punish_time=, reward_time=) against the reference's own
+    results for the same seeded drones: the airtime term switches sign / off, delta_t only scales the
+    returned time, timesteps bounds the episode."""
+    from learning_drones_amd.drone.drone import Drone
+    from learning_drones_amd.flight import fly
+    from learning_drones_amd.params import MlpSpec, unflatten_weights
+    spec = MlpSpec.from_hidden((10, 10))
+    for w, a, fin in zip(g7["weights"], g7["args"], g7["final"]):
+        d = Drone(visualize=False, n_servers=0)
+        d.controller.weights = unflatten_weights(w, spec)
+        reward, real_time, idx = fly(d, timesteps=int(a[0]), delta_t=float(a[1]), punish_time=bool(a[2]),
+                                     reward_time=bool(a[3]), idx=3)
+        assert (reward, idx, d.coins, d.flight_time, d.crashed) == (int(fin[0]), 3, int(fin[2]), int(fin[3]), bool(fin[4]))
+        assert abs(real_time - fin[1]) < 1e-9 and abs(d.distance_to_coin - fin[5]) < 1e-8
+    with pytest.raises(NotImplementedError):
+        fly(Drone(visualize=False, n_servers=0), visualize=True)

@@ -170,3 +170,16 @@ def test_population_threads_match_serial(oracle):
     a = oracle.fly(sim, ep, spec, genes, 300, n_threads=1)
     b = oracle.fly(sim, ep, spec, genes, 300, n_threads=4)
     assert np.array_equal(a.reward, b.reward) and np.array_equal(a.state, b.state)
+
+
+def test_fly_keyword_variants(oracle, g7):
+    """punish_time / reward_time / timesteps of fly() (flight/__init__.py:12-21,40-45)."""
+    sim = SimParams.reference()
+    spec = MlpSpec.from_hidden((10, 10))
+    for w, a, fin in zip(g7["weights"], g7["args"], g7["final"]):
+        T, punish, reward_t = int(a[0]), bool(a[2]), bool(a[3])
+        ep = EpisodeParams.reference(punish_time=punish, reward_time=reward_t)
+        r = oracle.fly(sim, ep, spec, w[None], T)
+        assert (int(r.reward[0]), int(r.coins[0]), int(r.flight_time[0]), int(r.crashed[0])) == \
+               (int(fin[0]), int(fin[2]), int(fin[3]), int(fin[4]))
+        assert abs(r.distance[0] - fin[5]) < 1e-9

@@ -27,6 +27,8 @@ def fly_population(drones: Sequence, timesteps: int = 2500, delta_t: float = 0.0
         return [], []
     precision = precision or getattr(drones[0], "precision", "f32")
     spec = drones[0].controller.spec
+    if any(d.controller.spec.hidden_widths != spec.hidden_widths for d in drones):
+        raise ValueError("fly_population needs one layer spec for the whole list (one genome array per population)")
     n = len(drones)
     coins = coin_chain_reference() if coins is None else coins
     pop = Population(n, spec.hidden_widths, precision=precision, coins=coins, walls=walls,

@@ -539,3 +539,30 @@ def test_limit_specs_and_tables(Population, oracle, hidden):
     assert np.median(np.abs(got32["flight_time"] - ref32.flight_time)) <= 1
     with pytest.raises(ValueError):
         MlpSpec.from_hidden((64, 64, 64, 64, 64))
+
+
+def test_large_angles_keep_accuracy(Population, oracle):
+    """Tumbling drones reach |angle| of hundreds of radians (angles are never wrapped,
+    drone/sensor/sensor.py:128-149): the float32 kernel's sin/cos must keep full range reduction.
+    One step from float32-representable states with angles up to +-3 000 rad, against the float64
+    closed form on the same inputs."""
+    rng = np.random.default_rng(77)
+    n = 4096
+    s = np.zeros((n, 12))
+    s[:, 2] = rng.uniform(5, 75, n)
+    s[:, 3:6] = rng.normal(0, 3, (n, 3))
+    s[:, 6:9] = rng.uniform(-3000, 3000, (n, 3))
+    s[:, 9:12] = rng.normal(0, 5, (n, 3))
+    s = s.astype(np.float32).astype(np.float64)
+    a = rng.normal(0, 5, (n, 6)).astype(np.float32).astype(np.float64)
+    u = rng.uniform(0, 1, (n, 4)).astype(np.float32).astype(np.float64)
+    pop = Population(n, (10, 10))
+    pop.set_state(s, a, u)
+    pop.measure()
+    got = pop.state_numpy()
+    sim, ep = SimParams.reference(), EpisodeParams.reference()
+    ref_s, ref_a, _, _ = oracle.measure(sim, ep, s, a, u, mode=oracle.CLOSED_F64)
+    tame = np.abs(np.cos(s[:, 7])) > 0.05
+    assert relerr(got[:, :12], ref_s, 1e-2) < RTOL_F32
+    assert relerr(got[tame, 12:15], ref_a[tame, :3], 1.0) < 1e-5        # linear accelerations: sin/cos products
+    assert relerr(got[tame, 15:18], ref_a[tame, 3:], 10.0) < 1e-4       # Euler-angle accelerations: 1/cos(pitch)

@@ -217,7 +217,9 @@ class DeviceEvolution:
             except RuntimeError as err:
                 self.exchange = "allgather"
                 if pop.rank == 0:
-                    print(f"[learning-drones_amd] all-to-all unavailable on this backend ({err}); using all-gather")
+                    import sys
+                    print(f"[learning-drones_amd] all-to-all unavailable on this backend ({err}); using all-gather",
+                          file=sys.stderr)
             self._alltoall_checked = True
         if pop.world > 1 and self.exchange == "alltoall":
             # only the selected parents travel (~1/W of an all-gather)

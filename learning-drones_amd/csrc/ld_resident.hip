@@ -10,7 +10,7 @@
 #define LD_RES_B 8
 #define LD_RES_C 8
 #endif
-#define LD_FOR_EACH_RESIDENT(X) X(LD_RES_A, 10, 10) X(LD_RES_B, 16, 16) X(LD_RES_C, 32, 32) X(64, 64, 64, 64)
+#define LD_FOR_EACH_RESIDENT(X) X(8, 8, 10) X(LD_RES_A, 10, 10) X(LD_RES_B, 16, 16) X(LD_RES_C, 32, 32) X(64, 64, 64, 64)
 
 template <int L, int... H> static bool resident_matches(const ld_mlp_spec& s) { return ld::NetShape<H...>::matches(s); }
 

@@ -208,7 +208,7 @@ class Population:
         _native.check(rc, "ld_fly_finalize")
         self._finalized = True
 
-    RESIDENT_SPECS = ((10, 10), (16, 16), (32, 32), (64, 64, 64))
+    RESIDENT_SPECS = ((8, 10), (10, 10), (16, 16), (32, 32), (64, 64, 64))
 
     def fly(self, timesteps: int = 2500, engine: str = "step"):
         """fly(drone, timesteps) for every drone, enqueued from C on the current stream.  Returns the

@@ -12,7 +12,7 @@ against a ~0.2 s rollout, so nothing is bucketed or overlapped.
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Tuple
 
 import numpy as np
 

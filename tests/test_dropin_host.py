@@ -1,8 +1,6 @@
 """Host-side drop-in parity (no GPU): the mirrors of Drone / NeuralNetwork / evolve.util draw from
 numpy's global random stream in the reference's order, so seeded runs reproduce the reference's
 genomes, selections, cuts and mutations bit for bit (golden G3 / G6)."""
-from types import SimpleNamespace
-
 import numpy as np
 import pytest
 

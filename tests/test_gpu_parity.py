@@ -11,7 +11,6 @@ Parity ladder:
   L4  populations: float32 kernels vs oracle float32, fraction of identical integer fitness
 """
 import ctypes as C
-import os
 
 import numpy as np
 import pytest

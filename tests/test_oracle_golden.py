@@ -2,8 +2,6 @@
 reference (tests/golden/make_golden.py).  This is what pins the oracle; everything the GPU
 tests assert is relative to it."""
 import numpy as np
-import pytest
-
 from learning_drones_amd.params import EpisodeParams, MlpSpec, SimParams
 
 # Episode 27 of G3 passes within ~1e-9 rad of the cos(pitch)=0 singularity of

@@ -227,8 +227,9 @@ int ld_fly_rollout_f64(const ld_sim_params *sim, const ld_episode_params *ep, co
 /* fly(drone, timesteps) with the genome RESIDENT in registers for the whole episode (float32):
  * ONE launch runs all `timesteps` iterations; each drone owns L lanes of a wavefront that share its
  * neurons, so the genes are read from HBM once per episode instead of once per step.  Same
- * arithmetic, bit-identical results to ld_fly_rollout_f32.  Available for the layer specs 8-10,
- * 10-10, 16-16, 32-32 and 64-64-64; any other spec returns LD_ERR_SPEC (use ld_fly_rollout_f32). */
+ * arithmetic, bit-identical results to ld_fly_rollout_f32.  Available for the layer specs that have an
+ * unrolled specialisation (8-10, 10-10, 16-16, 32-32, 64-64-64, 16, 32, 64, 8-8, 24-24, 48-48, 64-64,
+ * 32-32-32); any other spec returns LD_ERR_SPEC (use ld_fly_rollout_f32, which runs every spec). */
 int ld_fly_rollout_resident_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
                                 const double *coins, const double *walls, const float *genomes, float *fstate,
                                 int32_t *istate, ld_fitness_record *records, int64_t n, int32_t timesteps,

@@ -292,7 +292,9 @@ int launch_mlp(const ld_mlp_spec* spec, const Real* genomes, const Real* inputs,
 
 // Layer specs with an unrolled specialisation (tag, widths...); everything else takes the generic
 // kernel.  Each tag has its own translation unit ld_unrolled_<tag>.hip.
-#define LD_FOR_EACH_UNROLLED(X) X(8_10, 8, 10) X(10_10, 10, 10) X(16_16, 16, 16) X(32_32, 32, 32) X(64_64_64, 64, 64, 64)
+#define LD_FOR_EACH_UNROLLED(X)                                                                          \
+    X(8_10, 8, 10) X(10_10, 10, 10) X(16_16, 16, 16) X(32_32, 32, 32) X(64_64_64, 64, 64, 64)               \
+    X(16, 16) X(32, 32) X(64, 64) X(8_8, 8, 8) X(24_24, 24, 24) X(48_48, 48, 48) X(64_64, 64, 64) X(32_32_32, 32, 32, 32)
 
 #define LD_DECLARE_UNROLLED(TAG, ...)                                                                            \
     int ld_u_fly_f32_##TAG(const ld_sim_params*, const ld_episode_params*, const ld_mlp_spec*, const double*,    \

@@ -10,7 +10,9 @@
 #define LD_RES_B 8
 #define LD_RES_C 8
 #endif
-#define LD_FOR_EACH_RESIDENT(X) X(8, 8, 10) X(LD_RES_A, 10, 10) X(LD_RES_B, 16, 16) X(LD_RES_C, 32, 32) X(64, 64, 64, 64)
+#define LD_FOR_EACH_RESIDENT(X)                                                                          \
+    X(8, 8, 10) X(LD_RES_A, 10, 10) X(LD_RES_B, 16, 16) X(LD_RES_C, 32, 32) X(64, 64, 64, 64)               \
+    X(4, 16) X(4, 32) X(8, 64) X(4, 8, 8) X(8, 24, 24) X(16, 48, 48) X(32, 64, 64) X(16, 32, 32, 32)
 
 template <int L, int... H> static bool resident_matches(const ld_mlp_spec& s) { return ld::NetShape<H...>::matches(s); }
 

@@ -208,7 +208,9 @@ class Population:
         _native.check(rc, "ld_fly_finalize")
         self._finalized = True
 
-    RESIDENT_SPECS = ((8, 10), (10, 10), (16, 16), (32, 32), (64, 64, 64))
+    # layer specs with an unrolled step kernel and a resident engine (csrc/ld_kernels.hpp, ld_resident.hip)
+    RESIDENT_SPECS = ((8, 10), (10, 10), (16, 16), (32, 32), (64, 64, 64), (16,), (32,), (64,), (8, 8), (24, 24),
+                      (48, 48), (64, 64), (32, 32, 32))
 
     def fly(self, timesteps: int = 2500, engine: str = "step"):
         """fly(drone, timesteps) for every drone, enqueued from C on the current stream.  Returns the

@@ -131,7 +131,7 @@ def test_mlp_forward(Population, g2, precision, force_generic, monkeypatch):
 
 def test_mlp_generic_equals_unrolled(Population, torch, monkeypatch):
     rng = np.random.default_rng(3)
-    for hidden in ((8, 10), (10, 10), (16, 16), (32, 32), (64, 64, 64)):
+    for hidden in Population.RESIDENT_SPECS:
         n = 200                                                          # not a multiple of 64: tail lanes
         spec = MlpSpec.from_hidden(hidden)
         genes = rng.normal(0, 0.4, (n, spec.param_count))
@@ -424,7 +424,9 @@ def test_error_codes(Population):
 
 # ------------------------------------------------------------------------------------------- resident engine
 @pytest.mark.parametrize("hidden,n,T", [((32, 32), 1000, 600), ((16, 16), 1030, 2000), ((10, 10), 131, 2500),
-                                        ((64, 64, 64), 50, 300), ((8, 10), 77, 900)])
+                                        ((64, 64, 64), 50, 300), ((8, 10), 77, 900), ((16,), 70, 400), ((32,), 70, 400),
+                                        ((64,), 70, 400), ((8, 8), 70, 400), ((24, 24), 70, 400), ((48, 48), 70, 400),
+                                        ((64, 64), 70, 400), ((32, 32, 32), 70, 400)])
 def test_resident_engine_is_bit_identical(Population, torch, hidden, n, T):
     """The genome-resident whole-episode kernel (ld_fly_rollout_resident_f32) against the per-step
     contract kernel: same arithmetic in the same order, so states, rewards, coins, flight times and

@@ -169,7 +169,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ld_ga_select(C.byref(ga), C.byref(spec), fake, 8, 0, 0, None, None, None) == OK
     assert lib.ld_ga_select(C.byref(ga), C.byref(spec), None, 8, 0, 8, fake, fake, None) == NULL
     res = lib.ld_fly_rollout_resident_f32
-    unsupported = MlpSpec.from_hidden((12,))
+    unsupported = MlpSpec.from_hidden((12,))                 # no unrolled / resident specialisation
     assert res(C.byref(sim), C.byref(ep), C.byref(unsupported), fake, None, fake, fake, fake, fake, 8, 10, None) == SPEC
     assert res(C.byref(sim), C.byref(ep), C.byref(spec), None, None, None, None, None, None, 0, 10, None) == OK
     assert lib.ld_genome_words(C.byref(spec), 65) == 2 * 64 * 149 and lib.ld_genome_words(C.byref(spec), 0) == 0

@@ -250,6 +250,18 @@ def main():
             gen_dt = float(tmax.item())
     except RuntimeError as err:          # e.g. a backend without the collectives the generation step uses
         gen_error = str(err)[:200]
+    # the generation step's own kernels (select + breed, no communication): local shard bred from itself
+    from learning_drones_amd.params import GaParams
+    fit_local = pop.local.records[:, 0].contiguous()
+    b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    pop.local.breed(fit_local, GaParams.reference(seed=3))
+    b0.record()
+    for g in range(3):
+        pop.local.breed(fit_local, GaParams.reference(seed=3, generation=g + 1))
+    b1.record()
+    torch.cuda.synchronize()
+    breed_ms = b0.elapsed_time(b1) / 3
+    breed_gbs = 2 * 4 * pop.local.P * n_local / (breed_ms * 1e-3) / 1e9      # parent words read + child words written
 
     if rank == 0:
         n_total = n_local * world
@@ -272,7 +284,10 @@ def main():
             "generation": {"measured": n_gen, "includes": "rollout, record all-gather, elite, genome all-gather (N>1), "
                            "device select+breed (evolve/util.py + Drone.mutate semantics), reset; rollout engine: "
                            + evo.engine + ", parent exchange: " + (evo.exchange if world > 1 else "local"),
-                           "live_drone_step_fraction": gen_live, "error": gen_error},
+                           "live_drone_step_fraction": gen_live, "error": gen_error,
+                           "select_breed_ms": breed_ms, "select_breed_gbs": breed_gbs,
+                           "select_breed_note": "gather of 16-byte parent words at random drone indices + streaming "
+                                                "child stores; algorithmic 8P bytes per drone"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "copy_ceiling_gbs": copy_gbs,

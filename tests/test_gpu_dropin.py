@@ -373,3 +373,28 @@ def test_fly_keyword_variants(g7):
         assert abs(real_time - fin[1]) < 1e-9 and abs(d.distance_to_coin - fin[5]) < 1e-8
     with pytest.raises(NotImplementedError):
         fly(Drone(visualize=False, n_servers=0), visualize=True)
+
+
+def test_c_host_program_uses_the_abi_without_python(tmp_path):
+    """examples/c_host.c: plain C + hipMalloc against libld_drones.so — the boundary has no Python or
+    PyTorch in it.  Its printed record must equal what the Population wrapper gets for the same run."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    from learning_drones_amd.params import coin_chain_reference
+    from learning_drones_amd.population import Population
+    repo = Path(__file__).resolve().parent.parent
+    gcc = shutil.which("gcc")
+    exe = tmp_path / "c_host"
+    subprocess.check_call([gcc, str(repo / "examples" / "c_host.c"), f"-I{repo / 'include'}", "-I/opt/rocm/include",
+                           "-D__HIP_PLATFORM_AMD__", f"-L{repo / 'learning-drones_amd'}", "-lld_drones", "-L/opt/rocm/lib",
+                           "-lamdhip64", f"-Wl,-rpath,{repo / 'learning-drones_amd'}", "-Wl,-rpath,/opt/rocm/lib",
+                           "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True)
+    pop = Population(100, (16, 16), coins=coin_chain_reference(8))
+    pop.fly(500)
+    r = pop.results()[0]
+    want = (f"reward {int(r['reward'])} flight_time {int(r['flight_time'])} coins {int(r['coins'])} "
+            f"crashed {int(r['crashed'])} distance {float(r['distance_to_coin']):.4f}, all drones equal: yes")
+    assert want in out, out
+    assert int(r["crashed"]) == 1                    # zero genomes climb through the ceiling

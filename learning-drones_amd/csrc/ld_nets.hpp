@@ -22,6 +22,9 @@
 #ifndef LD_DEPTH_F32
 #define LD_DEPTH_F32 16
 #endif
+#ifndef LD_DEPTH_F32_SMALL_NET
+#define LD_DEPTH_F32_SMALL_NET 32
+#endif
 #ifndef LD_DEPTH_F64
 #define LD_DEPTH_F64 8
 #endif
@@ -99,8 +102,12 @@ template <int... H> struct NetShape {
 template <typename Real, bool Fma, int... H> struct UnrolledNet {
     using Shape = NetShape<H...>;
     static constexpr int kBlock = LD_UNROLLED_BLOCK;
-    // words in flight per lane: 16 x 16 B (float) / 8 x 32 B (double) = 16 KiB per wavefront
-    static constexpr int kWant = sizeof(Real) == 4 ? LD_DEPTH_F32 : LD_DEPTH_F64;
+    // words in flight per lane.  16 KiB per wavefront (16 float words) saturates HBM once every SIMD has
+    // a wavefront (>= 65 536 drones); below that the bytes in flight chip-wide set the rate (Little's
+    // law: 8 192 drones = 128 wavefronts x 16 KiB = 2 MiB / 0.67 us = 3.1 TB/s), so nets small enough to
+    // afford the registers keep 32 words in flight (8 192 drones: 4.0 TB/s, 16 384: 6.2 TB/s); more than
+    // 32 buys nothing (measured at 48 and 60).
+    static constexpr int kWant = sizeof(Real) == 4 ? (Shape::W <= 512 ? LD_DEPTH_F32_SMALL_NET : LD_DEPTH_F32) : LD_DEPTH_F64;
     static constexpr int kDepth = kWant < Shape::W ? kWant : Shape::W;
     struct Lds {};                               // no LDS use
     struct Ring { GeneWord<Real> slot[kDepth]; };

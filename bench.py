@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--hidden", type=str, default=",".join(map(str, WORKLOAD["hidden"])))
     ap.add_argument("--coins", type=int, default=WORKLOAD["n_coins"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline rollout and its roofline (for rocprofv3 "
+                    "runs: keeps every fly_step_kernel launch in the trace a full, live-population launch)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets several ranks share one "
                     "GPU to rehearse the N > 1 control flow on a one-GPU box")
     args = ap.parse_args()
@@ -183,17 +185,20 @@ def main():
     # The reference's own kind of population (random genomes, evolve/brain.py:24): every drone tumbles
     # and crashes within a few hundred steps; frozen wavefronts skip their gene traffic, so an episode
     # costs far less than N*T full drone-steps.  Informational (live drone-steps only are real work).
-    pop.local.init_genomes_reference(seed=7 + rank)
     random_pop = {}
-    for engine in ("step", "resident") if hidden in pop.local.RESIDENT_SPECS else ("step",):
+    engines = () if args.no_extras else (("step", "resident") if hidden in pop.local.RESIDENT_SPECS else ("step",))
+    if engines:
+        pop.local.init_genomes_reference(seed=7 + rank)
+    for engine in engines:
         pop.local.reset()
         fence()
         q0 = time.perf_counter()
         rec = pop.fly(T, engine=engine)
         fence()
         random_pop[engine + "_episode_ms"] = (time.perf_counter() - q0) * 1e3
-    random_pop["live_drone_step_fraction"] = float(rec[:, 1].double().sum().item()) / (rec.shape[0] * T)
-    pop.local.set_genomes(make_genomes(torch, n_local, hidden, device, seed=rank))
+    if engines:
+        random_pop["live_drone_step_fraction"] = float(rec[:, 1].double().sum().item()) / (rec.shape[0] * T)
+        pop.local.set_genomes(make_genomes(torch, n_local, hidden, device, seed=rank))
 
     # HBM bytes per launch from the PMC counters: collected by separate rocprofv3 --pmc passes of this
     # same command and committed under profiles/ (they cannot be read live); used only when the
@@ -208,7 +213,7 @@ def main():
     # The genome-resident engine (one launch per episode, genes held in registers: beyond the contract
     # of "one launch per timestep", bit-identical results) on the same workload, for reference.
     resident = None
-    if hidden in pop.local.RESIDENT_SPECS:
+    if hidden in pop.local.RESIDENT_SPECS and not args.no_extras:
         pop.local.reset()
         pop.fly(T, engine="resident")
         fence()
@@ -233,8 +238,10 @@ def main():
     # 1 / episode time; the live fraction of the measured generations is reported next to it.
     from learning_drones_amd.parallel import DeviceEvolution
     evo = DeviceEvolution(pop, seed=0x1D20)
-    n_gen, gen_live, gen_dt, gen_error = 3, 0.0, float("nan"), None
+    n_gen, gen_live, gen_dt, gen_error = 3, 0.0, float("nan"), ("skipped (--no-extras)" if args.no_extras else None)
     try:
+        if args.no_extras:
+            raise StopIteration
         pop.local.reset()
         evo.step(T)
         fence()
@@ -248,20 +255,24 @@ def main():
             tmax = torch.tensor([gen_dt], dtype=torch.float64, device=device)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             gen_dt = float(tmax.item())
+    except StopIteration:
+        pass
     except RuntimeError as err:          # e.g. a backend without the collectives the generation step uses
         gen_error = str(err)[:200]
     # the generation step's own kernels (select + breed, no communication): local shard bred from itself
     from learning_drones_amd.params import GaParams
-    fit_local = pop.local.records[:, 0].contiguous()
-    b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    pop.local.breed(fit_local, GaParams.reference(seed=3))
-    b0.record()
-    for g in range(3):
-        pop.local.breed(fit_local, GaParams.reference(seed=3, generation=g + 1))
-    b1.record()
-    torch.cuda.synchronize()
-    breed_ms = b0.elapsed_time(b1) / 3
-    breed_gbs = 2 * 4 * pop.local.P * n_local / (breed_ms * 1e-3) / 1e9      # parent words read + child words written
+    breed_ms = breed_gbs = None
+    if not args.no_extras:
+        fit_local = pop.local.records[:, 0].contiguous()
+        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        pop.local.breed(fit_local, GaParams.reference(seed=3))
+        b0.record()
+        for g in range(3):
+            pop.local.breed(fit_local, GaParams.reference(seed=3, generation=g + 1))
+        b1.record()
+        torch.cuda.synchronize()
+        breed_ms = b0.elapsed_time(b1) / 3
+        breed_gbs = 2 * 4 * pop.local.P * n_local / (breed_ms * 1e-3) / 1e9  # parent words read + child words written
 
     if rank == 0:
         n_total = n_local * world
@@ -296,7 +307,7 @@ def main():
                          "launch_us_isolated": isolated_launch_ms * 1e3,
                          "bytes_per_drone_step": pop.local.bytes_per_drone_step},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline(hidden, args.coins, T)
         print(json.dumps(out), flush=True)
     if dist:

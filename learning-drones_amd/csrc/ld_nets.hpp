@@ -178,6 +178,10 @@ template <typename Real, bool Fma, int... H> struct UnrolledNet {
 // ---------------------------------------------------------------------------------------------
 template <typename Real, bool Fma> struct GenericNet {
     static constexpr int kBlock = 64;
+    // NB the ring does not pipeline here: with the run-time cursor's branches in the loop body hipcc
+    // waits s_waitcnt vmcnt(0) before every word (verified in the ISA), so a deeper ring or fewer
+    // instructions per gene change nothing (2.1 TB/s at any depth 8-32, with or without a word-level
+    // fast path).  This kernel is the fallback for layer specs without an unrolled specialisation.
     static constexpr int kDepth = sizeof(Real) == 4 ? 8 : 4;
     struct Lds { Real act[2][LD_MAX_WIDTH][kBlock]; };
     struct Ring { GeneWord<Real> slot[kDepth]; };

@@ -1,0 +1,37 @@
+"""Soak test: the resident engine against the step engine on randomly drawn populations (sizes,
+layer specs, episode lengths, coin-table lengths, wall boxes, initial states).  Any difference in
+state, bookkeeping or records is an error.  usage: soak_engines.py [rounds]"""
+import sys
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np, torch
+from learning_drones_amd.population import Population
+from learning_drones_amd.params import coin_chain_reference
+from test_gpu_parity import _mixed_genomes
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(2024)
+bad = 0
+for r in range(rounds):
+    hidden = Population.RESIDENT_SPECS[rng.integers(len(Population.RESIDENT_SPECS))]
+    n = int(rng.choice([1, 5, 8, 63, 64, 65, 200, 1000, 4097]))
+    T = int(rng.integers(1, 1500))
+    coins = coin_chain_reference(int(rng.integers(1, 65)))
+    walls = None
+    if rng.random() < 0.5:
+        lo = rng.uniform(-10, 30, (int(rng.integers(1, 17)), 3)); lo[:, 2] = rng.uniform(0, 60, len(lo))
+        walls = np.concatenate([lo, lo + rng.uniform(0.5, 4, lo.shape)], axis=1)
+    init = np.array([rng.normal(0, 2), rng.normal(0, 2), rng.uniform(5, 40), *rng.normal(0, 1, 3), *rng.normal(0, 0.2, 3), *rng.normal(0, 1, 3)])
+    spec, genes, cls = _mixed_genomes(hidden, max(n, 3), seed=1000 + r)
+    genes = genes[:n]
+    out = []
+    for engine in ("step", "resident"):
+        pop = Population(n, hidden, coins=coins, walls=walls, init_state=init)
+        pop.set_genomes(genes)
+        pop.fly(T, engine=engine)
+        out.append((pop.fstate.clone(), pop.istate.clone(), pop.records.clone()))
+    same = all(torch.equal(a, b) for a, b in zip(*out))
+    crashed = float((out[0][1][2] & 1).float().mean())
+    print(f"round {r:3d} spec {str(hidden):14s} n={n:5d} T={T:5d} coins={len(coins):2d} walls={0 if walls is None else len(walls):2d} crashed {crashed:.2f}  {'ok' if same else 'MISMATCH'}", flush=True)
+    bad += not same
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)

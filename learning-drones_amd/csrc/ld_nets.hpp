@@ -178,11 +178,12 @@ template <typename Real, bool Fma, int... H> struct UnrolledNet {
 // ---------------------------------------------------------------------------------------------
 template <typename Real, bool Fma> struct GenericNet {
     static constexpr int kBlock = 64;
-    // NB the ring does not pipeline here: with the run-time cursor's branches in the loop body hipcc
-    // waits s_waitcnt vmcnt(0) before every word (verified in the ISA), so a deeper ring or fewer
-    // instructions per gene change nothing (2.1 TB/s at any depth 8-32, with or without a word-level
-    // fast path).  This kernel is the fallback for layer specs without an unrolled specialisation.
-    static constexpr int kDepth = sizeof(Real) == 4 ? 8 : 4;
+    // Words per chunk.  The gene stream is consumed in chunks of kDepth words held in registers while
+    // the loads of the next chunk are in flight: all loads of a chunk are issued at the top of the
+    // loop body and first needed at its bottom, a shape for which hipcc emits one s_waitcnt per chunk.
+    // (A ring refilled word by word, as in UnrolledNet, does not survive the run-time cursor's
+    // branches: the compiler then waits vmcnt(0) before every word and the kernel ran at 2.1 TB/s.)
+    static constexpr int kDepth = sizeof(Real) == 4 ? 16 : 8;
     struct Lds { Real act[2][LD_MAX_WIDTH][kBlock]; };
     struct Ring { GeneWord<Real> slot[kDepth]; };
 
@@ -196,6 +197,7 @@ template <typename Real, bool Fma> struct GenericNet {
 
     static __device__ __forceinline__ int words(const ld_mlp_spec& s) { return (int)((param_count(s) + 3) / 4); }
 
+    // first chunk
     static __device__ __forceinline__ void prefetch(const ld_mlp_spec& s, const GeneWord<Real>* __restrict__ genomes,
                                                     int64_t lane_offset, Ring& ring)
     {
@@ -217,12 +219,29 @@ template <typename Real, bool Fma> struct GenericNet {
         int layer = 0, n_in = LD_N_INPUTS, n_out = s.hidden[0], j = 0, k = 0, buf = 0;
         Real acc = (Real)0;
         for (int w0 = 0; w0 < W; w0 += kDepth) {
+            GeneWord<Real> next[kDepth];
+#pragma unroll
+            for (int i = 0; i < kDepth; ++i) {
+                const int w = w0 + kDepth + i;
+                next[i] = load_word<Real>(genomes, lane_offset, w < W ? w : W - 1);
+            }
 #pragma unroll
             for (int i = 0; i < kDepth; ++i) {
                 const int w = w0 + i;
                 if (w >= W) break;
                 const GeneWord<Real> v = ring.slot[i];
-                ring.slot[i] = load_word<Real>(genomes, lane_offset, (w + kDepth < W) ? w + kDepth : W - 1);
+                if (k + 4 <= n_in) {
+                    // most words: four weights of one neuron, no bias, no row change (same operations
+                    // in the same order as the gene-by-gene path below)
+                    const Real x0 = lds.act[buf][k][lane], x1 = lds.act[buf][k + 1][lane];
+                    const Real x2 = lds.act[buf][k + 2][lane], x3 = lds.act[buf][k + 3][lane];
+                    acc = mac<Real, Fma>(v.g[0], x0, k == 0 ? (Real)0 : acc);
+                    acc = mac<Real, Fma>(v.g[1], x1, acc);
+                    acc = mac<Real, Fma>(v.g[2], x2, acc);
+                    acc = mac<Real, Fma>(v.g[3], x3, acc);
+                    k += 4;
+                    continue;
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     if (4 * w + c >= P) break;
@@ -251,6 +270,8 @@ template <typename Real, bool Fma> struct GenericNet {
                     }
                 }
             }
+#pragma unroll
+            for (int i = 0; i < kDepth; ++i) ring.slot[i] = next[i];
         }
     }
 };

@@ -279,6 +279,11 @@ def main():
         breed_ms = b0.elapsed_time(b1) / 3
         breed_gbs = 2 * 4 * pop.local.P * n_local / (breed_ms * 1e-3) / 1e9  # parent words read + child words written
 
+    known = {(65536, 2000, (32, 32), 3): "BASELINE config 3", (1024, 2000, (16, 16), 1): "BASELINE config 2",
+             (32768, 4000, (32, 32), 3): "BASELINE config 4 (one GPU's shard)",
+             (131072, 4000, (64, 64, 64), 5): "BASELINE config 5 (one GPU's shard, no walls)"}
+    config_name = known.get((n_local, T, hidden, args.coins), "custom workload")
+
     if rank == 0:
         n_total = n_local * world
         value = n_total * T * args.steps / dt
@@ -287,7 +292,7 @@ def main():
             "value": value, "unit": "drone-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE config 3: {n_local} drones/GPU x {T} timesteps, 15-{'-'.join(map(str, hidden))}-4 "
+            "config": {"workload": f"{config_name}: {n_local} drones/GPU x {T} timesteps, 15-{'-'.join(map(str, hidden))}-4 "
                                    f"controller per drone, {args.coins}-coin chain, crash penalty; step = one episode "
                                    f"({T} fused-step launches + finalize" + (" + RCCL all-gather of fitness records)" if world > 1 else ")"),
                        "population": n_total, "timesteps": T, "hidden": list(hidden), "coins": args.coins,

@@ -76,3 +76,14 @@ def evolve(n_generations: int = n_generations, n_drones: int = n_drones, mutatio
         elite.reset()
         drones[0] = elite
     return global_best_drone, history
+
+
+if __name__ == "__main__":
+    # python -m learning_drones_amd.evolve.evolution  ==  python evolve/evolution.py of the reference
+    # (same hyper-parameters, evolution.py:16-20), with checkpoints under ./evolution/ as JSON
+    import os
+    execution_time = int(time())
+    os.makedirs("evolution", exist_ok=True)
+    best, _ = evolve(checkpoint=f"evolution/best_drone_{execution_time}.json")
+    save_drone(best, f"evolution/winning_drone_{execution_time}.json")
+    print(f"To reference this training, use execution time {execution_time}")

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define LD_ABI_VERSION 1
+#define LD_ABI_VERSION 2
 #define LD_N_INPUTS 15          /* evolve/brain.py:10 n_inputs: pos, vel, angle, angle_vel, coin */
 #define LD_N_OUTPUTS 4          /* four rotor thrust fractions */
 #define LD_MAX_HIDDEN_LAYERS 4
@@ -121,6 +121,15 @@ typedef struct ld_episode_params {
     int32_t n_coins;            /* rows of the coin table (1..LD_MAX_COINS) */
     int32_t n_walls;            /* rows of the wall table (0..LD_MAX_WALLS); build-defined extension,
                                    objects/walls.py is empty in the reference */
+    int32_t coin_respawn;       /* what follows the table's last row.  1: the reference's unbounded chain
+                                   (flight/__init__.py:47-52): every further coin spawns at the previous
+                                   position + (5, 2.5, 0) with radius 1 and value 1000, computed in the
+                                   kernel, so a one-row table {(5,5,10), r=2, 2000} IS the reference's
+                                   episode.  0: the chain ends with the table (BASELINE's "1 coin" /
+                                   "3 coins" / "5 coins" configurations): the last row stays the target
+                                   of the controller and of the distance penalty, nothing more is
+                                   collected. */
+    int32_t reserved;           /* 0 */
 } ld_episode_params;
 
 /* Controller shape: NeuralNetwork(layer_spec) (evolve/brain.py:10-24); the output layer
@@ -141,6 +150,9 @@ typedef struct ld_fitness_record {
 } ld_fitness_record;
 
 int ld_version(void);
+/* Test hook (process-wide, not part of the data path): non-zero routes every controller spec to the
+ * generic run-time-spec kernels even where an unrolled specialisation exists.  Returns the old value. */
+int ld_debug_force_generic(int on);
 const char *ld_strerror(int status);
 /* Text of the last HIP error seen by the calling thread ("" if none). */
 const char *ld_last_hip_error(void);
@@ -149,7 +161,8 @@ int ld_device_count(void);
 
 /* drone/quadcopter/parameters.py defaults (payload_set = None, no wind, dt = 0.01). */
 int ld_sim_params_default(ld_sim_params *out);
-/* drone/drone.py:12-17 constants; n_coins = 0, n_walls = 0 (caller sets the table sizes). */
+/* drone/drone.py:12-17 constants; n_coins = 0, n_walls = 0 (caller sets the table sizes),
+ * coin_respawn = 1 (the reference's unbounded chain). */
 int ld_episode_params_default(ld_episode_params *out);
 /* Fill a coin table by the rule of flight/__init__.py:25,47-52: first coin (5,5,10) r=2 value
  * 2000, each next one at +(5, 2.5, 0) with r=1 value 1000.  HOST pointer, n_coins rows. */
@@ -185,6 +198,16 @@ int ld_measure_f32(const ld_sim_params *sim, const ld_episode_params *ep,
 int ld_measure_f64(const ld_sim_params *sim, const ld_episode_params *ep,
                    double *fstate, int32_t *istate, int64_t n, void *stream);
 
+/* Replaces QuadcopterPhysics.calculate_accelerations (drone/quadcopter/physical_model.py:75-122,
+ * with lin_acc_drone_2_lab=True as every caller passes it: flight/__init__.py:35-37,
+ * drone/drone.py:131-136) for n drones: angle Real[3][n] (roll, pitch, yaw), thrust Real[4][n],
+ * wind from sim->wind; outputs lin_acc Real[3][n] (lab frame) and rot_acc Real[3][n] (Euler-angle
+ * accelerations).  _f64 keeps the reference's float32 rounding points, _f32 is the closed form. */
+int ld_accelerations_f32(const ld_sim_params *sim, const float *angle, const float *thrust,
+                         float *lin_acc, float *rot_acc, int64_t n, void *stream);
+int ld_accelerations_f64(const ld_sim_params *sim, const double *angle, const double *thrust,
+                         double *lin_acc, double *rot_acc, int64_t n, void *stream);
+
 /* Replaces NeuralNetwork.feed_forward (evolve/brain.py:41-54) for n independent genomes:
  * inputs Real[LD_N_INPUTS][n], outputs Real[LD_N_OUTPUTS][n]. */
 int ld_mlp_forward_f32(const ld_mlp_spec *spec, const float *genomes, const float *inputs,
@@ -203,6 +226,23 @@ int ld_fly_step_f32(const ld_sim_params *sim, const ld_episode_params *ep, const
 int ld_fly_step_f64(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
                     const double *coins, const double *walls, const double *genomes,
                     double *fstate, int32_t *istate, int64_t n, void *stream);
+
+/* `n_steps` iterations of that loop body in ONE launch (float32, layer specs with an unrolled
+ * specialisation; others return LD_ERR_SPEC), and the launch geometry made explicit:
+ * the 64 drones of a genome block are served by `waves_per_block` wavefronts of one workgroup (1, 2,
+ * 4 or 8; 0 = chosen from n so that the grid has at least one wavefront per SIMD).  Each wavefront
+ * streams a contiguous share of every layer's rows (still one lane per drone, one coalesced 1 KiB
+ * line per gene word, every neuron's sum in gene order), the layers' outputs cross wavefronts through
+ * LDS.  Small shards need this to fill the chip: 8 192 drones are 128 wavefronts at one lane per
+ * drone and one wavefront per block.  With n_steps > 1 the state stays in registers between steps
+ * and the genes are re-read every step (from L2 / Infinity Cache when the shard's genomes fit): the
+ * per-step launch boundary disappears, which is what bounds populations of a few thousand drones.
+ * Results are bit-identical to n_steps calls of ld_fly_step_f32 for every waves_per_block.
+ * ld_fly_step_f32 itself is ld_fly_steps_f32(..., 1, 0, stream) for those specs. */
+int ld_fly_steps_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
+                     const double *coins, const double *walls, const float *genomes,
+                     float *fstate, int32_t *istate, int64_t n, int32_t n_steps, int32_t waves_per_block,
+                     void *stream);
 
 /* The tail of fly() (flight/__init__.py:83-87,97-99): distance penalty -100*int(d) to the
  * current coin and the result record, for every drone (crashed ones kept the position they
@@ -223,6 +263,15 @@ int ld_fly_rollout_f64(const ld_sim_params *sim, const ld_episode_params *ep, co
                        const double *coins, const double *walls, const double *genomes,
                        double *fstate, int32_t *istate, ld_fitness_record *records,
                        double *distance_f64, int64_t n, int32_t timesteps, void *stream);
+
+/* As ld_fly_rollout_f32 with `steps_per_launch` loop iterations per launch (ld_fly_steps_f32;
+ * 1 = one launch per timestep, 0 = chosen from n and the spec: 1 unless the shard is small enough
+ * to be bound by the launch boundary) and `waves_per_block` as in ld_fly_steps_f32. */
+int ld_fly_rollout_steps_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
+                             const double *coins, const double *walls, const float *genomes,
+                             float *fstate, int32_t *istate, ld_fitness_record *records,
+                             int64_t n, int32_t timesteps, int32_t steps_per_launch, int32_t waves_per_block,
+                             void *stream);
 
 /* fly(drone, timesteps) with the genome RESIDENT in registers for the whole episode (float32):
  * ONE launch runs all `timesteps` iterations; each drone owns L lanes of a wavefront that share its

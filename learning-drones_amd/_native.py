@@ -25,8 +25,10 @@ EXPORTS = (
     "ld_mlp_forward_f32", "ld_mlp_forward_f64", "ld_fly_step_f32", "ld_fly_step_f64",
     "ld_fly_finalize_f32", "ld_fly_finalize_f64", "ld_fly_rollout_f32", "ld_fly_rollout_f64",
     "ld_ga_select", "ld_ga_breed_f32", "ld_ga_breed_f64", "ld_pid_episode_f32", "ld_pid_episode_f64",
-    "ld_fly_rollout_resident_f32",
+    "ld_fly_rollout_resident_f32", "ld_debug_force_generic", "ld_accelerations_f32", "ld_accelerations_f64",
+    "ld_fly_steps_f32", "ld_fly_rollout_steps_f32",
 )
+ABI_VERSION = 2
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -56,8 +58,8 @@ def lib() -> C.CDLL:
         if missing:
             raise NativeLibraryMissing(f"{path} lacks symbols {missing}; rebuild it")
         _declare(handle)
-        if handle.ld_version() != 1:
-            raise NativeLibraryMissing(f"{path}: ABI version {handle.ld_version()} != 1; rebuild it")
+        if handle.ld_version() != ABI_VERSION:
+            raise NativeLibraryMissing(f"{path}: ABI version {handle.ld_version()} != {ABI_VERSION}; rebuild it")
         _lib = handle
     return _lib
 
@@ -91,6 +93,11 @@ def _declare(h: C.CDLL) -> None:
     h.ld_fly_rollout_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, i64, i32, vp]
     h.ld_fly_rollout_f64.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]
     h.ld_fly_rollout_resident_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, i64, i32, vp]
+    h.ld_fly_steps_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, i64, i32, i32, vp]
+    h.ld_fly_rollout_steps_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
+    h.ld_accelerations_f32.argtypes = [sim, vp, vp, vp, vp, i64, vp]
+    h.ld_accelerations_f64.argtypes = [sim, vp, vp, vp, vp, i64, vp]
+    h.ld_debug_force_generic.argtypes = [C.c_int]
     ga = C.POINTER(GaParams)
     h.ld_ga_select.argtypes = [ga, spec, vp, i64, i64, i64, vp, vp, vp]
     h.ld_ga_breed_f32.argtypes = [ga, spec, vp, i64, i32, vp, vp, vp, i64, i64, vp, vp]

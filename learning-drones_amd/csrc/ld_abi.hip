@@ -1,10 +1,19 @@
 // ld_abi.hip — the C ABI of include/ld_drones.h: argument checks, dispatch to the unrolled
 // specialisations (ld_unrolled_*.hip) or the generic kernels, and the small kernels' launches.
+#include <atomic>
 #include <cstdlib>
 
 #include "ld_ga.hpp"
 #include "ld_kernels.hpp"
 #include "ld_pid.hpp"
+#include "ld_split.hpp"
+
+#ifndef LD_MULTISTEP_MAX_BYTES
+#define LD_MULTISTEP_MAX_BYTES (8 << 20)
+#endif
+#ifndef LD_MULTISTEP_STEPS
+#define LD_MULTISTEP_STEPS 16
+#endif
 
 int ld_resident_dispatch(const ld_sim_params*, const ld_episode_params*, const ld_mlp_spec*, const double*, const double*,
                          const float*, float*, int32_t*, int64_t, int32_t, hipStream_t);          // ld_resident.hip
@@ -16,6 +25,8 @@ using ld::launch_fly_step;
 using ld::launch_mlp;
 
 namespace {
+
+std::atomic<int> g_force_generic{0};          // ld_debug_force_generic: the library's only process-wide state
 
 int check_spec(const ld_mlp_spec* spec)
 {
@@ -43,7 +54,7 @@ int dispatch_fly_step(const ld_sim_params* sim, const ld_episode_params* ep, con
                       const double* coins, const double* walls, const Real* genomes, Real* fstate,
                       int32_t* istate, int64_t n, hipStream_t stream)
 {
-    if (!getenv("LD_FORCE_GENERIC")) {
+    if (!g_force_generic.load(std::memory_order_relaxed)) {
 #define X(TAG, ...)                                                                                          \
         if (spec_is<__VA_ARGS__>(*spec)) {                                                                   \
             if constexpr (sizeof(Real) == 4)                                                                 \
@@ -62,7 +73,7 @@ template <typename Real, bool Fma>
 int dispatch_mlp(const ld_mlp_spec* spec, const Real* genomes, const Real* inputs, Real* outputs, int64_t n,
                  hipStream_t stream)
 {
-    if (!getenv("LD_FORCE_GENERIC")) {
+    if (!g_force_generic.load(std::memory_order_relaxed)) {
 #define X(TAG, ...)                                                                                          \
         if (spec_is<__VA_ARGS__>(*spec)) {                                                                   \
             if constexpr (sizeof(Real) == 4) return ld_u_mlp_f32_##TAG(spec, genomes, inputs, outputs, n, stream); \
@@ -74,21 +85,70 @@ int dispatch_mlp(const ld_mlp_spec* spec, const Real* genomes, const Real* input
     return launch_mlp<Real, ld::GenericNet<Real, Fma>>(spec, genomes, inputs, outputs, n, stream);
 }
 
-template <typename Real, bool Faithful>
-int fly_step_impl(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,
-                  const double* coins, const double* walls, const Real* genomes, Real* fstate,
-                  int32_t* istate, int64_t n, void* stream)
+// Wavefronts per 64-drone genome block for the split kernel (ld_split.hpp): the most that still fits the
+// grid into one round of resident wavefronts -- 1 024 at L <= 4 (a wavefront of those kernels owns its
+// SIMD's registers), 2 048 at L = 8.
+int auto_waves_per_block(int64_t n)
+{
+    const int64_t blocks = (n + 63) / 64;
+    if (blocks * 8 <= 2048) return 8;
+    if (blocks * 4 <= 1024) return 4;
+    if (blocks * 2 <= 1024) return 2;
+    return 1;
+}
+
+// n_steps loop iterations in one launch, float32, unrolled specs only (LD_ERR_SPEC otherwise).
+int dispatch_split_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec, const double* coins,
+                       const double* walls, const float* genomes, float* fstate, int32_t* istate, int64_t n,
+                       int32_t n_steps, int32_t waves, hipStream_t stream)
+{
+    if (waves == 0) waves = auto_waves_per_block(n);
+#define X(TAG, ...)                                                                                          \
+    if (spec_is<__VA_ARGS__>(*spec))                                                                         \
+        return ld_u_split_f32_##TAG(sim, ep, coins, walls, genomes, fstate, istate, n, n_steps, waves, stream);
+    LD_FOR_EACH_UNROLLED(X)
+#undef X
+    return LD_ERR_SPEC;
+}
+
+bool has_unrolled(const ld_mlp_spec& spec)
+{
+    if (g_force_generic.load(std::memory_order_relaxed)) return false;
+#define X(TAG, ...) if (spec_is<__VA_ARGS__>(spec)) return true;
+    LD_FOR_EACH_UNROLLED(X)
+#undef X
+    return false;
+}
+
+int check_fly_args(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec, const double* coins,
+                   const double* walls, const void* genomes, const void* fstate, const void* istate, int64_t n)
 {
     if (!sim) return LD_ERR_NULL;
     int rc = check_spec(spec);
     if (rc) return rc;
     if (!ep) return LD_ERR_NULL;
     if (n < 0) return LD_ERR_SIZE;
-    if (n == 0) return LD_OK;                       // an empty population is a no-op
+    if (n == 0) return LD_OK;
     rc = check_episode(ep, coins, walls);
     if (rc) return rc;
     if (!genomes || !fstate || !istate) return LD_ERR_NULL;
     if (!aligned16(genomes)) return LD_ERR_ALIGN;
+    return LD_OK;
+}
+
+template <typename Real, bool Faithful>
+int fly_step_impl(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,
+                  const double* coins, const double* walls, const Real* genomes, Real* fstate,
+                  int32_t* istate, int64_t n, void* stream)
+{
+    const int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
+    if (rc || n == 0) return rc;                    // an empty population is a no-op
+    if constexpr (sizeof(Real) == 4) {
+        static const bool legacy = getenv("LD_STEP_LEGACY") != nullptr;       // A/B switch, read once
+        if (!legacy && has_unrolled(*spec))
+            return dispatch_split_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, 1, 0,
+                                      static_cast<hipStream_t>(stream));
+    }
     return dispatch_fly_step<Real, Faithful>(sim, ep, spec, coins, walls, genomes, fstate, istate, n,
                                              static_cast<hipStream_t>(stream));
 }
@@ -105,8 +165,36 @@ int finalize_impl(const ld_episode_params* ep, const double* coins, const Real* 
     ld_episode_params e = *ep;
     e.n_walls = 0;
     hipLaunchKernelGGL((ld::finalize_kernel<Real>), dim3(blocks_for(n, 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), e, coins, fstate, istate, records, distance_f64, n);
+                       static_cast<hipStream_t>(stream), ld::make_ep<Real>(e), coins, fstate, istate, records, distance_f64, n);
     return check_launch("finalize_kernel");
+}
+
+// Loop iterations per launch chosen for a shard: 1 (the contract: one launch advances the population one
+// timestep) unless a launch moves so few bytes that the kernel boundary (~1.5-2 us) would dominate it.
+int auto_steps_per_launch(const ld_mlp_spec* spec, int64_t n)
+{
+    const int64_t bytes = n * (4 * ld_mlp_param_count(spec) + 200);
+    return bytes <= (int64_t)LD_MULTISTEP_MAX_BYTES ? LD_MULTISTEP_STEPS : 1;
+}
+
+int rollout_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec, const double* coins,
+                      const double* walls, const float* genomes, float* fstate, int32_t* istate,
+                      ld_fitness_record* records, int64_t n, int32_t timesteps, int32_t steps_per_launch, int32_t waves,
+                      void* stream)
+{
+    if (timesteps < 0 || steps_per_launch < 0) return LD_ERR_SIZE;
+    if (waves != 0 && waves != 1 && waves != 2 && waves != 4 && waves != 8) return LD_ERR_SIZE;
+    int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
+    if (rc || n == 0) return rc;
+    if (!has_unrolled(*spec)) return LD_ERR_SPEC;
+    if (steps_per_launch == 0) steps_per_launch = auto_steps_per_launch(spec, n);
+    for (int32_t t = 0; t < timesteps; t += steps_per_launch) {
+        const int32_t k = timesteps - t < steps_per_launch ? timesteps - t : steps_per_launch;
+        rc = dispatch_split_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, k, waves,
+                                static_cast<hipStream_t>(stream));
+        if (rc) return rc;
+    }
+    return finalize_impl<float>(ep, coins, fstate, istate, records, nullptr, n, stream);
 }
 
 template <typename Real, bool Faithful>
@@ -115,6 +203,11 @@ int rollout_impl(const ld_sim_params* sim, const ld_episode_params* ep, const ld
                  ld_fitness_record* records, double* distance_f64, int64_t n, int32_t timesteps, void* stream)
 {
     if (timesteps < 0) return LD_ERR_SIZE;
+    if constexpr (sizeof(Real) == 4) {
+        static const bool legacy = getenv("LD_STEP_LEGACY") != nullptr;
+        if (!legacy && spec && check_spec(spec) == LD_OK && has_unrolled(*spec))
+            return rollout_steps_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, records, n, timesteps, 0, 0, stream);
+    }
     for (int32_t t = 0; t < timesteps; ++t) {
         const int rc = fly_step_impl<Real, Faithful>(sim, ep, spec, coins, walls, genomes, fstate, istate, n, stream);
         if (rc) return rc;
@@ -131,8 +224,21 @@ int measure_impl(const ld_sim_params* sim, const ld_episode_params* ep, Real* fs
     if (n == 0) return LD_OK;
     if (!fstate || !istate) return LD_ERR_NULL;
     hipLaunchKernelGGL((ld::measure_kernel<Real, Faithful>), dim3(blocks_for(n, 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), *sim, *ep, fstate, istate, n);
+                       static_cast<hipStream_t>(stream), ld::make_sim<Real>(*sim), ld::make_ep<Real>(*ep), fstate, istate, n);
     return check_launch("measure_kernel");
+}
+
+template <typename Real, bool Faithful>
+int accelerations_impl(const ld_sim_params* sim, const Real* angle, const Real* thrust, Real* lin_acc, Real* rot_acc,
+                       int64_t n, void* stream)
+{
+    if (!sim) return LD_ERR_NULL;
+    if (n < 0) return LD_ERR_SIZE;
+    if (n == 0) return LD_OK;
+    if (!angle || !thrust || !lin_acc || !rot_acc) return LD_ERR_NULL;
+    hipLaunchKernelGGL((ld::accelerations_kernel<Real, Faithful>), dim3(blocks_for(n, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), ld::make_sim<Real>(*sim), angle, thrust, lin_acc, rot_acc, n);
+    return check_launch("accelerations_kernel");
 }
 
 template <typename Real, bool Fma>
@@ -208,8 +314,8 @@ int pid_impl(const ld_sim_params* sim, const Real* gains, const double* coins, i
     if (n == 0) return LD_OK;
     if (!gains || !coins || !fstate || !score || !target || !steps) return LD_ERR_NULL;
     hipLaunchKernelGGL((ld::pid_episode_kernel<Real, Faithful>), dim3(blocks_for(n, 64)), dim3(64), 0,
-                       static_cast<hipStream_t>(stream), *sim, gains, coins, n_coins, coin_radius, coin_value, timesteps,
-                       fstate, score, target, steps, trace, n);
+                       static_cast<hipStream_t>(stream), ld::make_sim<Real>(*sim), gains, coins, n_coins, coin_radius, coin_value,
+                       timesteps, fstate, score, target, steps, trace, n);
     return check_launch("pid_episode_kernel");
 }
 
@@ -273,6 +379,38 @@ int ld_ga_breed_f64(const ld_ga_params* ga, const ld_mlp_spec* spec, const doubl
 
 int ld_version(void) { return LD_ABI_VERSION; }
 
+int ld_debug_force_generic(int on) { return g_force_generic.exchange(on ? 1 : 0); }
+
+int ld_accelerations_f32(const ld_sim_params* sim, const float* angle, const float* thrust, float* lin_acc, float* rot_acc,
+                         int64_t n, void* stream)
+{ return accelerations_impl<float, false>(sim, angle, thrust, lin_acc, rot_acc, n, stream); }
+int ld_accelerations_f64(const ld_sim_params* sim, const double* angle, const double* thrust, double* lin_acc,
+                         double* rot_acc, int64_t n, void* stream)
+{ return accelerations_impl<double, true>(sim, angle, thrust, lin_acc, rot_acc, n, stream); }
+
+int ld_fly_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec, const double* coins,
+                     const double* walls, const float* genomes, float* fstate, int32_t* istate, int64_t n, int32_t n_steps,
+                     int32_t waves_per_block, void* stream)
+{
+    if (n_steps < 0) return LD_ERR_SIZE;
+    if (waves_per_block != 0 && waves_per_block != 1 && waves_per_block != 2 && waves_per_block != 4 && waves_per_block != 8)
+        return LD_ERR_SIZE;
+    const int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
+    if (rc || n == 0 || n_steps == 0) return rc;
+    if (!has_unrolled(*spec)) return LD_ERR_SPEC;
+    return dispatch_split_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, n_steps, waves_per_block,
+                              static_cast<hipStream_t>(stream));
+}
+
+int ld_fly_rollout_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,
+                             const double* coins, const double* walls, const float* genomes, float* fstate,
+                             int32_t* istate, ld_fitness_record* records, int64_t n, int32_t timesteps,
+                             int32_t steps_per_launch, int32_t waves_per_block, void* stream)
+{
+    return rollout_steps_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, records, n, timesteps, steps_per_launch,
+                             waves_per_block, stream);
+}
+
 const char* ld_strerror(int status)
 {
     switch (status) {
@@ -320,6 +458,7 @@ int ld_episode_params_default(ld_episode_params* e)
     e->angle_limit = 3.14159265358979323846 / 4; e->angle_vel_limit = 20;
     e->z_floor = 0; e->z_ceiling = 80;
     e->n_coins = 0; e->n_walls = 0;
+    e->coin_respawn = 1; e->reserved = 0;
     return LD_OK;
 }
 

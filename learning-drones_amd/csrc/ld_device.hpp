@@ -38,12 +38,51 @@ template <> struct Math<double> {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Uniform blocks in the kernel's own arithmetic type.  The C ABI hands over ld_sim_params /
+// ld_episode_params (doubles, host memory); the launch helpers convert them ONCE on the host, so a
+// float32 kernel receives float kernel arguments (half the SGPRs, no v_cvt_f32_f64 per wave per step).
+// (Real)x of a double on the host and on the device are the same correctly rounded value, so results
+// do not change.  The device functions below are templated on the block's type and accept either.
+// ---------------------------------------------------------------------------------------------
+template <typename Real> struct SimT {
+    Real mass_total, gravity_force, coef_force, coef_moment, coef_wind, radius_motor;
+    Real inv_inertia[3], moments_payload[3], wind[3];
+    Real dt;
+};
+template <typename Real> struct EpT {
+    int32_t reward_time, reward_crashed, reward_unstable, reward_distance;
+    Real angle_limit, angle_vel_limit, z_floor, z_ceiling;
+    int32_t n_coins, n_walls, coin_respawn;
+};
+template <typename Real> inline SimT<Real> make_sim(const ld_sim_params& p)
+{
+    SimT<Real> s;
+    s.mass_total = (Real)p.mass_total; s.gravity_force = (Real)p.gravity_force; s.coef_force = (Real)p.coef_force;
+    s.coef_moment = (Real)p.coef_moment; s.coef_wind = (Real)p.coef_wind; s.radius_motor = (Real)p.radius_motor;
+    for (int i = 0; i < 3; ++i) {
+        s.inv_inertia[i] = (Real)p.inv_inertia[i]; s.moments_payload[i] = (Real)p.moments_payload[i]; s.wind[i] = (Real)p.wind[i];
+    }
+    s.dt = (Real)p.dt;
+    return s;
+}
+template <typename Real> inline EpT<Real> make_ep(const ld_episode_params& e)
+{
+    EpT<Real> r;
+    r.reward_time = e.reward_time; r.reward_crashed = e.reward_crashed; r.reward_unstable = e.reward_unstable;
+    r.reward_distance = e.reward_distance;
+    r.angle_limit = (Real)e.angle_limit; r.angle_vel_limit = (Real)e.angle_vel_limit;
+    r.z_floor = (Real)e.z_floor; r.z_ceiling = (Real)e.z_ceiling;
+    r.n_coins = e.n_coins; r.n_walls = e.n_walls; r.coin_respawn = e.coin_respawn;
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Accelerations, closed form: with Rot = (Rz Ry Rx)^T
 //   a_lin = (Rz Ry Rx)[:,2] * sum(T)/m - [0,0,G/m] + wind * c_w/m
 //   a_rot = Tr(roll, pitch) * (([L,M,N] + M_p) * 1/I)
 // ---------------------------------------------------------------------------------------------
-template <typename Real>
-__device__ __forceinline__ void accel_closed(const ld_sim_params& p, const Real ang[3], const Real u[4],
+template <typename Real, typename Sim>
+__device__ __forceinline__ void accel_closed(const Sim& p, const Real ang[3], const Real u[4],
                                              Real lin[3], Real rot[3])
 {
     Real sr, cr, sp, cp, sy, cy;
@@ -88,7 +127,8 @@ __device__ __forceinline__ double dot3_gemv_c(double a0, double b0, double a1, d
     return ::fma(a2, b2, ::fma(a0, b0, a1 * b1));
 }
 
-__device__ __forceinline__ void accel_faithful(const ld_sim_params& p, const double ang[3], const double u[4],
+template <typename Sim>
+__device__ __forceinline__ void accel_faithful(const Sim& p, const double ang[3], const double u[4],
                                                double lin[3], double rot[3])
 {
     const double roll = ang[0], pitch = ang[1], yaw = ang[2];
@@ -144,15 +184,15 @@ __device__ __forceinline__ void accel_faithful(const ld_sim_params& p, const dou
         rot[i] = dot3_gemv_c((double)Tr[i][0], b[0], (double)Tr[i][1], b[1], (double)Tr[i][2], b[2]);
 }
 
-template <typename Real, bool Faithful>
-__device__ __forceinline__ void accelerations(const ld_sim_params& p, const Real ang[3], const Real u[4],
+template <typename Real, bool Faithful, typename Sim>
+__device__ __forceinline__ void accelerations(const Sim& p, const Real ang[3], const Real u[4],
                                               Real lin[3], Real rot[3])
 {
     if constexpr (Faithful) {
         static_assert(sizeof(Real) == 8, "the faithful path is float64");
         accel_faithful(p, ang, u, lin, rot);
     } else {
-        accel_closed<Real>(p, ang, u, lin, rot);
+        accel_closed<Real, Sim>(p, ang, u, lin, rot);
     }
 }
 
@@ -175,8 +215,8 @@ template <typename Real> struct DroneRegs {
 
 // drone/drone.py:129-165 (+ build-defined wall boxes held in LDS).  Returns true if crashed;
 // `reward` receives the crash / instability terms.
-template <typename Real, bool Faithful>
-__device__ __forceinline__ bool measure(const ld_sim_params& sim, const ld_episode_params& ep,
+template <typename Real, bool Faithful, typename Sim, typename Ep>
+__device__ __forceinline__ bool measure(const Sim& sim, const Ep& ep,
                                         const Real* __restrict__ lds_walls, DroneRegs<Real>& d, int32_t& reward)
 {
     Real lin[3], rot[3];
@@ -207,6 +247,29 @@ __device__ __forceinline__ Real coin_distance(const Real* __restrict__ coin, con
 {
     const Real dx = coin[0] - s[0], dy = coin[1] - s[1], dz = coin[2] - s[2];
     return Math<Real>::sqrt((dx * dx + dy * dy) + dz * dz);               // objects/coins.py:17-25
+}
+
+// The coin a drone that has collected `ncoll` coins is flying to (flight/__init__.py:25,47-52).  Rows of the
+// table first.  Beyond the table, with ep.coin_respawn, the reference's respawn rule applied to the last
+// row: position + (5, 2.5, 0) per further coin, radius 1, value 1000 -- the reference's unbounded chain
+// (every coordinate is a small multiple of 2.5, so the product equals the reference's repeated additions
+// exactly, in float32 too).  Without coin_respawn the chain ends with the table: the target stays the last
+// row and nothing more can be collected.  Returns whether the coin can still be collected.
+template <typename Real, typename Ep>
+__device__ __forceinline__ bool current_coin(const Ep& ep, const Real* __restrict__ table, int32_t ncoll, Real c[LD_COIN_STRIDE])
+{
+    const int last = ep.n_coins - 1;
+    const Real* row = table + (ncoll < ep.n_coins ? ncoll : last) * LD_COIN_STRIDE;
+#pragma unroll
+    for (int k = 0; k < LD_COIN_STRIDE; ++k) c[k] = row[k];
+    if (ncoll < ep.n_coins) return true;
+    if (!ep.coin_respawn) return false;
+    const Real extra = (Real)(ncoll - last);
+    c[0] = c[0] + (Real)5 * extra;
+    c[1] = c[1] + (Real)2.5 * extra;
+    c[3] = (Real)1;
+    c[4] = (Real)1000;
+    return true;
 }
 
 // Activation functions of evolve/brain.py:26-39.

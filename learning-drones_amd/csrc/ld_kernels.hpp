@@ -37,13 +37,54 @@ template <typename Real> struct Tables {
     Real walls[LD_MAX_WALLS * LD_WALL_STRIDE];
 };
 
-template <typename Real>
-__device__ __forceinline__ void stage_tables(Tables<Real>& t, const ld_episode_params& ep,
+template <typename Real, typename Ep>
+__device__ __forceinline__ void stage_tables(Tables<Real>& t, const Ep& ep,
                                              const double* __restrict__ coins, const double* __restrict__ walls)
 {
     for (int i = threadIdx.x; i < ep.n_coins * LD_COIN_STRIDE; i += blockDim.x) t.coins[i] = (Real)coins[i];
     for (int i = threadIdx.x; i < ep.n_walls * LD_WALL_STRIDE; i += blockDim.x) t.walls[i] = (Real)walls[i];
 }
+
+// The same staging in two halves, so that the table loads can be issued BEFORE a gene prefetch and
+// consumed after it: a thread holds its (at most 5 + 2) table entries in registers in between.
+template <int Block> struct TableRegs {
+    static constexpr int kCoins = (LD_MAX_COINS * LD_COIN_STRIDE + Block - 1) / Block;
+    static constexpr int kWalls = (LD_MAX_WALLS * LD_WALL_STRIDE + Block - 1) / Block;
+    double c[kCoins], w[kWalls];
+    template <typename Ep>
+    __device__ __forceinline__ void load(const Ep& ep, const double* __restrict__ coins, const double* __restrict__ walls)
+    {
+        // unconditional loads at clamped indices (a predicated load sits in its own basic block and the
+        // compiler then waits for it on the spot, serialising the state and gene latencies)
+        const int n_c = ep.n_coins * LD_COIN_STRIDE, n_w = ep.n_walls * LD_WALL_STRIDE;
+        const double* wsrc = n_w > 0 ? walls : coins;             // walls may be NULL when there are none
+        const int last_w = n_w > 0 ? n_w - 1 : 0;
+#pragma unroll
+        for (int q = 0; q < kCoins; ++q) {
+            const int idx = threadIdx.x + q * Block;
+            c[q] = coins[idx < n_c ? idx : n_c - 1];
+        }
+#pragma unroll
+        for (int q = 0; q < kWalls; ++q) {
+            const int idx = threadIdx.x + q * Block;
+            w[q] = wsrc[idx < n_w ? idx : last_w];
+        }
+    }
+    template <typename Real, typename Ep>
+    __device__ __forceinline__ void store(const Ep& ep, Tables<Real>& t) const
+    {
+#pragma unroll
+        for (int q = 0; q < kCoins; ++q) {
+            const int idx = threadIdx.x + q * Block;
+            if (idx < ep.n_coins * LD_COIN_STRIDE) t.coins[idx] = (Real)c[q];
+        }
+#pragma unroll
+        for (int q = 0; q < kWalls; ++q) {
+            const int idx = threadIdx.x + q * Block;
+            if (idx < ep.n_walls * LD_WALL_STRIDE) t.walls[idx] = (Real)w[q];
+        }
+    }
+};
 
 template <typename Real>
 __device__ __forceinline__ void load_drone(const Real* __restrict__ fstate, int64_t n, int64_t i, DroneRegs<Real>& d)
@@ -72,7 +113,7 @@ __device__ __forceinline__ void store_drone(Real* __restrict__ fstate, int64_t n
 // ---------------------------------------------------------------------------------------------
 template <typename Real, bool Faithful, typename Net>
 __global__ void __launch_bounds__(Net::kBlock)
-fly_step_kernel(const ld_sim_params sim, const ld_episode_params ep, const ld_mlp_spec spec,
+fly_step_kernel(const SimT<Real> sim, const EpT<Real> ep, const ld_mlp_spec spec,
                 const double* __restrict__ coins, const double* __restrict__ walls,
                 const GeneWord<Real>* __restrict__ genomes, Real* __restrict__ fstate,
                 int32_t* __restrict__ istate, const int64_t n)
@@ -83,25 +124,27 @@ fly_step_kernel(const ld_sim_params sim, const ld_episode_params ep, const ld_ml
     const bool valid = gid < n;
     const int64_t i = valid ? gid : n - 1;                    // tail lanes read drone n-1, store nothing
 
-    // Issue every independent load first: status, genome prefetch, state, tables.
+    // Issue every independent load before anything waits: the drone's own words FIRST, the gene
+    // prefetch after them.  s_waitcnt vmcnt counts in issue order, so the physics below can start
+    // as soon as the 25 state words are in, with the whole gene ring still in flight behind them.
     const int32_t status = istate[(int64_t)LD_I_STATUS * n + i];
-    typename Net::Ring ring;
-    const int64_t lane_offset = word_index(i, 0, Net::words(spec));
-    Net::prefetch(spec, genomes, lane_offset, ring);
     int32_t reward = istate[(int64_t)LD_I_REWARD * n + i];
     int32_t ncoll = istate[(int64_t)LD_I_COINS * n + i];
     DroneRegs<Real> d;
     load_drone<Real>(fstate, n, i, d);
+    typename Net::Ring ring;
+    const int64_t lane_offset = word_index(i, 0, Net::words(spec));
+    Net::prefetch(spec, genomes, lane_offset, ring);
     stage_tables<Real>(tab, ep, coins, walls);
     __syncthreads();
 
     const bool dead = (status & 1) || !valid;                 // crashed earlier: frozen
-    if (__all(dead)) return;                                  // whole wavefront frozen: no gene traffic
+    if (__all(dead)) return;                                  // whole wavefront frozen: only the ring's first words were requested
 
     const int32_t flight_time = (status >> 1) + 1;            // flight/__init__.py:45
     reward += ep.reward_time;                                 // :41-44
-    if (ncoll < ep.n_coins) {                                 // :47-52, test against the pre-step position
-        const Real* c = tab.coins + ncoll * LD_COIN_STRIDE;
+    Real c[LD_COIN_STRIDE];
+    if (current_coin<Real>(ep, tab.coins, ncoll, c)) {        // :47-52, test against the pre-step position
         if (coin_distance<Real>(c, d.s) < c[3]) {
             reward += (int32_t)c[4];
             ncoll += 1;
@@ -110,12 +153,12 @@ fly_step_kernel(const ld_sim_params sim, const ld_episode_params ep, const ld_ml
     const bool crashed = measure<Real, Faithful>(sim, ep, tab.walls, d, reward);   // :79
 
     // :89 controller on the post-step state; its output acts at the next step
-    const int cur = ncoll < ep.n_coins ? ncoll : ep.n_coins - 1;
+    current_coin<Real>(ep, tab.coins, ncoll, c);
     Real x[LD_N_INPUTS], y[LD_N_OUTPUTS];
 #pragma unroll
     for (int k = 0; k < 12; ++k) x[k] = d.s[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) x[12 + k] = tab.coins[cur * LD_COIN_STRIDE + k];
+    for (int k = 0; k < 3; ++k) x[12 + k] = c[k];
     Net::forward(spec, net_lds, genomes, lane_offset, ring, x, y);
     // a select, not a branch: under `if (!crashed)` the compiler sinks the output layer and its
     // gene loads into the conditional block, past the pinned pipeline
@@ -132,7 +175,7 @@ fly_step_kernel(const ld_sim_params sim, const ld_episode_params ep, const ld_ml
 // Drone.measure for every live drone (drone/drone.py:129-165).
 template <typename Real, bool Faithful>
 __global__ void __launch_bounds__(256)
-measure_kernel(const ld_sim_params sim, const ld_episode_params ep, Real* __restrict__ fstate,
+measure_kernel(const SimT<Real> sim, const EpT<Real> ep, Real* __restrict__ fstate,
                int32_t* __restrict__ istate, const int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -142,7 +185,7 @@ measure_kernel(const ld_sim_params sim, const ld_episode_params ep, Real* __rest
     int32_t reward = istate[(int64_t)LD_I_REWARD * n + i];
     DroneRegs<Real> d;
     load_drone<Real>(fstate, n, i, d);
-    ld_episode_params e = ep;
+    EpT<Real> e = ep;
     e.n_walls = 0;                                            // the bare reference semantics
     const bool crashed = measure<Real, Faithful>(sim, e, nullptr, d, reward);
     store_drone<Real>(fstate, n, i, d);
@@ -173,10 +216,28 @@ mlp_forward_kernel(const ld_mlp_spec spec, const GeneWord<Real>* __restrict__ ge
     }
 }
 
+// QuadcopterPhysics.calculate_accelerations for n drones (drone/quadcopter/physical_model.py:75-122).
+template <typename Real, bool Faithful>
+__global__ void __launch_bounds__(256)
+accelerations_kernel(const SimT<Real> sim, const Real* __restrict__ angle, const Real* __restrict__ thrust,
+                     Real* __restrict__ lin_acc, Real* __restrict__ rot_acc, const int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Real a[3], u[4], lin[3], rot[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a[k] = angle[(int64_t)k * n + i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = thrust[(int64_t)k * n + i];
+    accelerations<Real, Faithful>(sim, a, u, lin, rot);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { lin_acc[(int64_t)k * n + i] = lin[k]; rot_acc[(int64_t)k * n + i] = rot[k]; }
+}
+
 // Tail of fly() (flight/__init__.py:83-87,97-99).
 template <typename Real>
 __global__ void __launch_bounds__(256)
-finalize_kernel(const ld_episode_params ep, const double* __restrict__ coins, const Real* __restrict__ fstate,
+finalize_kernel(const EpT<Real> ep, const double* __restrict__ coins, const Real* __restrict__ fstate,
                 int32_t* __restrict__ istate, ld_fitness_record* __restrict__ records,
                 double* __restrict__ distance_f64, const int64_t n)
 {
@@ -190,8 +251,9 @@ finalize_kernel(const ld_episode_params ep, const double* __restrict__ coins, co
     for (int f = 0; f < 3; ++f) s[f] = fstate[(int64_t)(LD_F_POS + f) * n + i];
     const int32_t ncoll = istate[(int64_t)LD_I_COINS * n + i];
     const int32_t status = istate[(int64_t)LD_I_STATUS * n + i];
-    const int cur = ncoll < ep.n_coins ? ncoll : ep.n_coins - 1;
-    const Real dist = coin_distance<Real>(tab.coins + cur * LD_COIN_STRIDE, s);
+    Real c[LD_COIN_STRIDE];
+    current_coin<Real>(ep, tab.coins, ncoll, c);
+    const Real dist = coin_distance<Real>(c, s);
     const int32_t reward = istate[(int64_t)LD_I_REWARD * n + i] + ep.reward_distance * (int32_t)dist;   // int() truncates
     istate[(int64_t)LD_I_REWARD * n + i] = reward;
     if (records) {
@@ -274,7 +336,7 @@ int launch_fly_step(const ld_sim_params* sim, const ld_episode_params* ep, const
                     int32_t* istate, int64_t n, hipStream_t stream)
 {
     hipLaunchKernelGGL((fly_step_kernel<Real, Faithful, Net>), dim3(blocks_for(n, Net::kBlock)), dim3(Net::kBlock),
-                       0, stream, *sim, *ep, *spec, coins, walls,
+                       0, stream, make_sim<Real>(*sim), make_ep<Real>(*ep), *spec, coins, walls,
                        reinterpret_cast<const GeneWord<Real>*>(genomes), fstate, istate, n);
     return check_launch("fly_step_kernel");
 }

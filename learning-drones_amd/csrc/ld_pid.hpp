@@ -38,7 +38,7 @@ template <typename Real> __device__ __forceinline__ Real clamp01(Real v) { retur
 // fstate as everywhere; score/target/steps: int32[n]; trace (optional): Real[T][16][n] = state12 + thrust4.
 template <typename Real, bool Faithful>
 __global__ void __launch_bounds__(64)
-pid_episode_kernel(const ld_sim_params sim, const Real* __restrict__ gains, const double* __restrict__ coins,
+pid_episode_kernel(const SimT<Real> sim, const Real* __restrict__ gains, const double* __restrict__ coins,
                    const int32_t n_coins, const double coin_radius, const int32_t coin_value, const int32_t timesteps,
                    Real* __restrict__ fstate, int32_t* __restrict__ score_out, int32_t* __restrict__ target_out,
                    int32_t* __restrict__ steps_out, Real* __restrict__ trace, const int64_t n)

@@ -46,7 +46,7 @@ template <int L, int... H> struct ResidentLayout {
 #endif
 template <int L, int... H>
 __global__ void __launch_bounds__(64, LD_RES_WAVES)
-fly_resident_kernel(const ld_sim_params sim, const ld_episode_params ep, const double* __restrict__ coins,
+fly_resident_kernel(const SimT<float> sim, const EpT<float> ep, const double* __restrict__ coins,
                     const double* __restrict__ walls, const float* __restrict__ genomes, float* __restrict__ fstate,
                     int32_t* __restrict__ istate, const int64_t n, const int32_t timesteps)
 {
@@ -94,20 +94,20 @@ fly_resident_kernel(const ld_sim_params sim, const ld_episode_params ep, const d
         // ---- flight/__init__.py:41-52, :79 (identical to fly_step_kernel)
         int32_t r = reward + ep.reward_time;
         int32_t nc = ncoll;
-        if (nc < ep.n_coins) {
-            const float* c = tab.coins + nc * LD_COIN_STRIDE;
+        float c[LD_COIN_STRIDE];
+        if (current_coin<float>(ep, tab.coins, nc, c)) {
             if (coin_distance<float>(c, d.s) < c[3]) { r += (int32_t)c[4]; nc += 1; }
         }
         DroneRegs<float> e = d;
         const bool crashed = measure<float, false>(sim, ep, tab.walls, e, r);
-        const int cur = nc < ep.n_coins ? nc : ep.n_coins - 1;
+        current_coin<float>(ep, tab.coins, nc, c);
 
         // ---- controller (evolve/brain.py:41-54): lane l owns neurons l, l+L, ... of every layer
         float act[MW];
 #pragma unroll
         for (int k = 0; k < 12; ++k) act[k] = e.s[k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) act[12 + k] = tab.coins[cur * LD_COIN_STRIDE + k];
+        for (int k = 0; k < 3; ++k) act[12 + k] = c[k];
         static_for<0, Shape::n_layers>([&](auto lc) __attribute__((always_inline)) {
             constexpr int layer = decltype(lc)::value;
             constexpr int n_in = Shape::dims[layer], n_out = Shape::dims[layer + 1];
@@ -169,7 +169,8 @@ int launch_fly_resident(const ld_sim_params* sim, const ld_episode_params* ep, c
                         const float* genomes, float* fstate, int32_t* istate, int64_t n, int32_t timesteps, hipStream_t stream)
 {
     constexpr int G = 64 / L;
-    hipLaunchKernelGGL((fly_resident_kernel<L, H...>), dim3(blocks_for(n, G)), dim3(64), 0, stream, *sim, *ep, coins, walls,
+    hipLaunchKernelGGL((fly_resident_kernel<L, H...>), dim3(blocks_for(n, G)), dim3(64), 0, stream, make_sim<float>(*sim),
+                       make_ep<float>(*ep), coins, walls,
                        genomes, fstate, istate, n, timesteps);
     return check_launch("fly_resident_kernel");
 }

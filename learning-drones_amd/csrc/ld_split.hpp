@@ -1,0 +1,321 @@
+// ld_split.hpp — the fused fly() step with a genome block's 64 drones served by L wavefronts, and
+// with any number of loop iterations per launch.
+//
+// fly_step_kernel (ld_kernels.hpp) gives a 64-drone genome block ONE wavefront.  That fills the chip
+// from 65 536 drones up (1 024 blocks = one wavefront per SIMD); a shard of 8 192 drones -- what one
+// GPU owns when BASELINE's 65 536-drone population is spread over 8 -- is 128 wavefronts on 1 024
+// SIMDs and runs at the rate its bytes in flight allow (4.0 TB/s), and 1 024 drones are bound by the
+// launch boundary.  Here a block's workgroup has L wavefronts.  The lane is still the drone and a
+// gene word is still one coalesced 1 KiB line per wavefront, but wavefront k of the workgroup streams
+// only rows [k*n_out/L, (k+1)*n_out/L) of every layer (a contiguous piece of the block's gene region)
+// and the layer outputs cross wavefronts through LDS as [neuron][lane] (bank-conflict free) behind an
+// s_barrier.  Every neuron's sum still runs over its inputs in gene order on one lane, so results are
+// bit-identical to the one-wavefront kernel for every L.  The rigid-body step is computed by all L
+// wavefronts alike (22 state words against the 1 700 genes of a 32-32 net; a second copy of the
+// state in L2-hit loads is cheaper than a barrier in front of the first layer); wavefront 0 stores.
+//
+// n_steps > 1 keeps the drone state in registers between iterations and re-streams the genes every
+// step (they come from L2 / Infinity Cache when the shard's genomes fit there): no per-step kernel
+// boundary and no state traffic, for the populations small enough to be bound by those.
+//
+// Reference semantics are exactly fly_step_kernel's (flight/__init__.py:39-89).
+#pragma once
+
+#include "ld_kernels.hpp"
+
+namespace ld {
+
+// Which rows, which gene words and which positions of its private word stream wavefront k has.
+template <int L, int... H> struct SplitPlan {
+    using Shape = NetShape<H...>;
+    static constexpr int NL = Shape::n_layers;
+    static constexpr int row_begin(int layer, int k) { return k * Shape::dims[layer + 1] / L; }
+    static constexpr int row_end(int layer, int k) { return (k + 1) * Shape::dims[layer + 1] / L; }
+    static constexpr int gene_begin(int layer, int k) { return Shape::layer_offset(layer) + row_begin(layer, k) * (Shape::dims[layer] + 1); }
+    static constexpr int gene_end(int layer, int k) { return Shape::layer_offset(layer) + row_end(layer, k) * (Shape::dims[layer] + 1); }
+    static constexpr int word_begin(int layer, int k) { return gene_begin(layer, k) / 4; }
+    static constexpr int word_end(int layer, int k)            // exclusive; a word shared with a neighbour is loaded by both
+    {
+        return row_end(layer, k) == row_begin(layer, k) ? word_begin(layer, k) : (gene_end(layer, k) + 3) / 4;
+    }
+    static constexpr int stream_pos(int layer, int k)
+    {
+        int s = 0;
+        for (int l = 0; l < layer; ++l) s += word_end(l, k) - word_begin(l, k);
+        return s;
+    }
+    static constexpr int stream_len(int k) { return stream_pos(NL, k); }
+    static constexpr int max_stream_len()
+    {
+        int m = 0;
+        for (int k = 0; k < L; ++k) m = stream_len(k) > m ? stream_len(k) : m;
+        return m;
+    }
+    static constexpr int word_at(int k, int s)                  // gene word at stream position s
+    {
+        for (int l = 0; l < NL; ++l) {
+            const int len = word_end(l, k) - word_begin(l, k);
+            if (s < len) return word_begin(l, k) + s;
+            s -= len;
+        }
+        return 0;
+    }
+    // rows of the exchange buffer: one per neuron of every layer
+    static constexpr int xch_row(int layer)
+    {
+        int r = 0;
+        for (int l = 0; l < layer; ++l) r += Shape::dims[l + 1];
+        return r;
+    }
+    static constexpr int xch_rows = L > 1 ? xch_row(NL) : 1;
+};
+
+// f(integral_constant<K>) for the K that equals `wave` (wave-uniform), as a switch:
+// with independent ifs the compiler must assume that a later block can run after an earlier one and
+// puts an s_waitcnt vmcnt(0) in front of it for the ring registers both write.
+template <int L, typename F>
+__device__ __forceinline__ void wave_switch(int wave, F&& f)
+{
+    static_assert(L <= 8, "extend the switch");
+#define LD_WAVE_CASE(K)                                                 \
+    case K:                                                             \
+        if constexpr (K < L) f(std::integral_constant<int, K>{});       \
+        break;
+    switch (wave) {
+        LD_WAVE_CASE(0) LD_WAVE_CASE(1) LD_WAVE_CASE(2) LD_WAVE_CASE(3)
+        LD_WAVE_CASE(4) LD_WAVE_CASE(5) LD_WAVE_CASE(6) LD_WAVE_CASE(7)
+    default: break;
+    }
+#undef LD_WAVE_CASE
+}
+
+template <int L, typename F>
+__device__ __forceinline__ void wave_ifs(int wave, F&& f)
+{
+    static_for<0, L>([&](auto kc) __attribute__((always_inline)) {
+        if (wave == decltype(kc)::value) f(kc);
+    });
+}
+#ifndef LD_PREFETCH_DISPATCH
+#define LD_PREFETCH_DISPATCH wave_switch
+#endif
+#ifndef LD_FORWARD_DISPATCH
+#define LD_FORWARD_DISPATCH wave_switch
+#endif
+
+// LDS writes of this wavefront done, then the workgroup barrier.  Not __syncthreads(): its fences may
+// drain vmcnt, and the gene ring must stay in flight across the layer boundaries.
+__device__ __forceinline__ void split_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Ring depth caps: a wavefront has 512 registers at L <= 4 (one wavefront per SIMD), 256 at L = 8.
+#ifndef LD_SPLIT_DEPTH_CAP
+#define LD_SPLIT_DEPTH_CAP 32
+#endif
+#ifndef LD_SPLIT_DEPTH_CAP_L8
+#define LD_SPLIT_DEPTH_CAP_L8 16
+#endif
+#ifndef LD_SPLIT_HEAD_L8
+#define LD_SPLIT_HEAD_L8 8
+#endif
+
+template <typename Real, bool Faithful, int L, int... H>
+__global__ void __launch_bounds__(64 * L)
+fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restrict__ coins,
+                 const double* __restrict__ walls, const GeneWord<Real>* __restrict__ genomes,
+                 Real* __restrict__ fstate, int32_t* __restrict__ istate, const int64_t n, const int32_t n_steps)
+{
+    using Plan = SplitPlan<L, H...>;
+    using Shape = typename Plan::Shape;
+    constexpr int NL = Shape::n_layers;
+    constexpr int MW = Shape::max_width();
+    constexpr bool Fma = !Faithful;
+    // words in flight per lane (ld_nets.hpp: 32 for the small nets, 16 for the 64-wide ones), within the
+    // registers a wavefront has when 2 of them share a SIMD (L = 8: 256)
+    constexpr int kWantBase = sizeof(Real) == 4 ? (Shape::W <= 512 ? LD_DEPTH_F32_SMALL_NET : LD_DEPTH_F32) : LD_DEPTH_F64;
+    constexpr int kCap = L >= 8 ? LD_SPLIT_DEPTH_CAP_L8 : LD_SPLIT_DEPTH_CAP;
+    constexpr int kWant = kWantBase < kCap ? kWantBase : kCap;
+    constexpr int D = kWant < Plan::max_stream_len() ? kWant : Plan::max_stream_len();
+
+    __shared__ Tables<Real> tab;
+    __shared__ Real xch[Plan::xch_rows][64];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = L == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t gid = (int64_t)blockIdx.x * 64 + lane;
+    const bool valid = gid < n;
+    const int64_t i = valid ? gid : n - 1;                    // tail lanes read drone n-1, store nothing
+
+    // the drone's own words first, the gene ring behind them (vmcnt counts in issue order: the physics
+    // can start as soon as the state is in, with the ring still in flight)
+    const int32_t status_loaded = istate[(int64_t)LD_I_STATUS * n + i];
+    int32_t reward = istate[(int64_t)LD_I_REWARD * n + i];
+    int32_t ncoll = istate[(int64_t)LD_I_COINS * n + i];
+    DroneRegs<Real> d;
+    load_drone<Real>(fstate, n, i, d);
+    int64_t lane_offset = word_index(i, 0, Shape::W);
+    TableRegs<64 * L> table_regs;                             // coin / wall tables: requested now, staged below
+    table_regs.load(ep, coins, walls);
+
+    // ---- this wavefront's first D gene words, requested behind the state and the tables
+    GeneWord<Real> ring[D];
+    // In two parts where registers are short (L = 8: 256 per wavefront): the first kHead words go out
+    // before the rigid-body step, whose sincosf needs ~80 registers of its own, the rest right after it.
+    constexpr int kHead = L >= 8 ? (D < LD_SPLIT_HEAD_L8 ? D : LD_SPLIT_HEAD_L8) : D;
+    auto prefetch = [&](auto part) __attribute__((always_inline)) {
+        constexpr int A = decltype(part)::value == 0 ? 0 : kHead;
+        constexpr int B = decltype(part)::value == 0 ? kHead : D;
+        LD_PREFETCH_DISPATCH<L>(wave, [&](auto kc) __attribute__((always_inline)) {
+            constexpr int K = decltype(kc)::value;
+            constexpr int N = Plan::stream_len(K);
+            static_for<A, (B < N ? B : N)>([&](auto sc) __attribute__((always_inline)) {
+                constexpr int s = decltype(sc)::value;
+                ring[s] = load_word<Real>(genomes, lane_offset, Plan::word_at(K, s));
+            });
+        });
+    };
+    // One prefetch site only (at the top of the loop body): with a second one behind the last layer the
+    // register allocator keeps two copies of the ring.
+    bool dead0 = false, dead = false;
+    int32_t flight_time = 0;
+    for (int32_t t = 0; t < n_steps; ++t) {
+        if (t > 0 && __all(dead)) break;                      // every wavefront of the block sees the same 64 drones
+        prefetch(std::integral_constant<int, 0>{});
+        // Nothing above may wait: everything below that reads a loaded value stays below this line (the
+        // laundered status keeps the compiler from hoisting the frozen test in front of the prefetch,
+        // where its s_waitcnt would serialise the state latency and the gene latency).
+        __builtin_amdgcn_sched_barrier(0);
+        if (t == 0) {
+            int32_t status = status_loaded;
+            asm volatile("" : "+v"(status));
+            table_regs.template store<Real>(ep, tab);         // older than the ring: waits for state + tables only
+            split_barrier();
+            dead0 = (status & 1) || !valid;                   // crashed earlier: frozen
+            dead = dead0;
+            flight_time = status >> 1;
+            if (__all(dead)) break;                           // block frozen before this launch
+        }
+        // ---- flight/__init__.py:41-52, :79
+        int32_t r = reward + ep.reward_time;
+        int32_t nc = ncoll;
+        Real c[LD_COIN_STRIDE];
+        if (current_coin<Real>(ep, tab.coins, nc, c)) {
+            if (coin_distance<Real>(c, d.s) < c[3]) { r += (int32_t)c[4]; nc += 1; }
+        }
+        DroneRegs<Real> e = d;
+        const bool crashed = measure<Real, Faithful>(sim, ep, tab.walls, e, r);
+        // commit the step now (a drone that crashed earlier keeps the state it crashed with, :80-87), so
+        // that only one copy of the state is live while the controller runs; the thrusts follow below
+        const bool was_dead = dead;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) d.s[k] = was_dead ? d.s[k] : e.s[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d.acc[k] = was_dead ? d.acc[k] : e.acc[k];
+        reward = was_dead ? reward : r;
+        ncoll = was_dead ? ncoll : nc;
+        flight_time += was_dead ? 0 : 1;
+        dead = was_dead || crashed;
+        current_coin<Real>(ep, tab.coins, ncoll, c);
+
+        if constexpr (kHead < D) prefetch(std::integral_constant<int, 1>{});
+
+        // ---- controller on the post-step state (evolve/brain.py:41-54); frozen lanes compute on their
+        // frozen state and discard the result
+        Real act[MW];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) act[k] = d.s[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) act[12 + k] = c[k];
+        LD_FORWARD_DISPATCH<L>(wave, [&](auto kc) __attribute__((always_inline)) {
+            constexpr int K = decltype(kc)::value;
+            {
+                constexpr int N = Plan::stream_len(K);
+                static_for<0, NL>([&](auto lc) __attribute__((always_inline)) {
+                    constexpr int layer = decltype(lc)::value;
+                    constexpr int n_in = Shape::dims[layer], n_out = Shape::dims[layer + 1];
+                    constexpr bool last = layer == NL - 1;
+                    constexpr int r0 = Plan::row_begin(layer, K), r1 = Plan::row_end(layer, K);
+                    constexpr int g0 = Plan::gene_begin(layer, K), g1 = Plan::gene_end(layer, K);
+                    constexpr int wa = Plan::word_begin(layer, K), wb = Plan::word_end(layer, K);
+                    constexpr int base = Plan::stream_pos(layer, K);
+                    Real out[r1 > r0 ? r1 - r0 : 1];
+                    Real acc = (Real)0;
+                    static_for<wa, wb>([&](auto wc) __attribute__((always_inline)) {
+                        constexpr int w = decltype(wc)::value;
+                        constexpr int s = base + (w - wa);
+                        // the software pipeline of UnrolledNet::forward (ld_nets.hpp): nothing moves across the
+                        // sched_barrier, and the refill's address depends on this word's result
+                        __builtin_amdgcn_sched_barrier(0);
+                        const GeneWord<Real> v = ring[s % D];
+                        static_for<0, 4>([&](auto cc) __attribute__((always_inline)) {
+                            constexpr int cidx = decltype(cc)::value;
+                            constexpr int p = 4 * w + cidx;
+                            if constexpr (p >= g0 && p < g1) {
+                                constexpr int q = p - Shape::layer_offset(layer);
+                                constexpr int j = q / (n_in + 1), k = q % (n_in + 1);
+                                if constexpr (k == 0) {
+                                    acc = mac<Real, Fma>(v.g[cidx], act[0], (Real)0);
+                                } else if constexpr (k < n_in) {
+                                    acc = mac<Real, Fma>(v.g[cidx], act[k], acc);
+                                } else {
+                                    acc = acc + v.g[cidx];
+                                    out[j - r0] = last ? sigmoid04<Real>(acc) : relu<Real>(acc);
+                                }
+                            }
+                        });
+                        if constexpr (s + D < N) {
+                            asm volatile("" : "+v"(lane_offset) : "v"(acc));
+                            ring[s % D] = load_word<Real>(genomes, lane_offset, Plan::word_at(K, s + D));
+                        }
+                    });
+                    if constexpr (L == 1) {
+#pragma unroll
+                        for (int j = 0; j < n_out; ++j) act[j] = out[j];
+                    } else {
+#pragma unroll
+                        for (int j = r0; j < r1; ++j) xch[Plan::xch_row(layer) + j][lane] = out[j - r0];
+                        split_barrier();
+#pragma unroll
+                        for (int j = 0; j < n_out; ++j) act[j] = xch[Plan::xch_row(layer) + j][lane];
+                    }
+                });
+            }
+        });
+        // an unconditional use of the outputs (see UnrolledNet::forward)
+        asm volatile("" ::"v"(act[0]), "v"(act[1]), "v"(act[2]), "v"(act[3]));
+
+        // the controller's output acts at the next step (:89); none after a crash
+#pragma unroll
+        for (int k = 0; k < LD_N_OUTPUTS; ++k) d.u[k] = dead ? d.u[k] : act[k];
+    }
+    if (!dead0 && wave == 0) {
+        // a laundered copy of the index: otherwise the 25 load addresses stay live in 50 registers through
+        // the whole kernel just to be reused here
+        int64_t is = i;
+        asm volatile("" : "+v"(is));
+        store_drone<Real>(fstate, n, is, d);
+        istate[(int64_t)LD_I_REWARD * n + is] = reward;
+        istate[(int64_t)LD_I_COINS * n + is] = ncoll;
+        istate[(int64_t)LD_I_STATUS * n + is] = 2 * flight_time + (dead ? 1 : 0);
+    }
+}
+
+template <typename Real, bool Faithful, int L, int... H>
+int launch_fly_split(const ld_sim_params* sim, const ld_episode_params* ep, const double* coins, const double* walls,
+                     const Real* genomes, Real* fstate, int32_t* istate, int64_t n, int32_t n_steps, hipStream_t stream)
+{
+    hipLaunchKernelGGL((fly_split_kernel<Real, Faithful, L, H...>), dim3(blocks_for(n, 64)), dim3(64 * L), 0, stream,
+                       make_sim<Real>(*sim), make_ep<Real>(*ep), coins, walls,
+                       reinterpret_cast<const GeneWord<Real>*>(genomes), fstate, istate, n, n_steps);
+    return check_launch("fly_split_kernel");
+}
+
+}  // namespace ld
+
+// One function per unrolled spec (ld_split_<tag>.hip): dispatch on the wavefronts per block.
+#define LD_DECLARE_SPLIT(TAG, ...)                                                                                \
+    int ld_u_split_f32_##TAG(const ld_sim_params*, const ld_episode_params*, const double*, const double*,        \
+                             const float*, float*, int32_t*, int64_t, int32_t, int32_t, hipStream_t);
+LD_FOR_EACH_UNROLLED(LD_DECLARE_SPLIT)

@@ -1,0 +1,3 @@
+#define LD_TAG 32_32_32
+#define LD_WIDTHS 32, 32, 32
+#include "ld_split.inc"

@@ -1,0 +1,3 @@
+#define LD_TAG 64_64_64
+#define LD_WIDTHS 64, 64, 64
+#include "ld_split.inc"

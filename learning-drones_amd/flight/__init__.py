@@ -6,7 +6,7 @@ from typing import Sequence
 
 import numpy as np
 
-from ..params import EpisodeParams, SimParams, coin_chain_reference
+from ..params import EpisodeParams, SimParams
 
 
 def _check_episode_args(delta_t, visualize, n_servers):
@@ -30,7 +30,6 @@ def fly_population(drones: Sequence, timesteps: int = 2500, delta_t: float = 0.0
     if any(d.controller.spec.hidden_widths != spec.hidden_widths for d in drones):
         raise ValueError("fly_population needs one layer spec for the whole list (one genome array per population)")
     n = len(drones)
-    coins = coin_chain_reference() if coins is None else coins
     pop = Population(n, spec.hidden_widths, precision=precision, coins=coins, walls=walls,
                      episode=EpisodeParams.reference(punish_time=punish_time, reward_time=reward_time),
                      sim=SimParams.reference())

@@ -71,11 +71,15 @@ class EpisodeParams(C.Structure):
         ("reward_time", C.c_int32), ("reward_crashed", C.c_int32), ("reward_unstable", C.c_int32),
         ("reward_distance", C.c_int32), ("angle_limit", C.c_double), ("angle_vel_limit", C.c_double),
         ("z_floor", C.c_double), ("z_ceiling", C.c_double), ("n_coins", C.c_int32), ("n_walls", C.c_int32),
+        ("coin_respawn", C.c_int32), ("reserved", C.c_int32),
     ]
 
     @classmethod
-    def reference(cls, *, punish_time=False, reward_time=True, n_coins=MAX_COINS, n_walls=0) -> "EpisodeParams":
-        """drone/drone.py:12-17; punish_time / reward_time as in fly() (flight/__init__.py:41-44)."""
+    def reference(cls, *, punish_time=False, reward_time=True, n_coins=1, n_walls=0, coin_respawn=True) -> "EpisodeParams":
+        """drone/drone.py:12-17; punish_time / reward_time as in fly() (flight/__init__.py:41-44).
+        coin_respawn=True continues the chain beyond the table by the reference's rule
+        (flight/__init__.py:47-52: +(5, 2.5, 0), radius 1, value 1000), without bound; False ends the
+        chain with the table's last row (BASELINE's "1 coin" / "3 coins" / "5 coins" configurations)."""
         e = cls()
         e.reward_time = 2 * (int(bool(reward_time)) - int(bool(punish_time)))
         e.reward_crashed = -3000
@@ -85,6 +89,7 @@ class EpisodeParams(C.Structure):
         e.angle_vel_limit = 20.0
         e.z_floor, e.z_ceiling = 0.0, 80.0
         e.n_coins, e.n_walls = n_coins, n_walls
+        e.coin_respawn, e.reserved = int(bool(coin_respawn)), 0
         return e
 
 
@@ -169,7 +174,9 @@ CRASHED_BIT = 1 << 30
 def coin_chain_reference(n_coins: int = MAX_COINS) -> np.ndarray:
     """Coin table [n][5] = x, y, z, radius, value by the rule of flight/__init__.py:25,47-52:
     first coin (5, 5, 10) r=2 worth 2000, each next one at +(5, 2.5, 0), r=1, worth 1000.
-    The reference's chain is unbounded; MAX_COINS rows (the last at x = 320 m) stand in for it."""
+    The reference's chain is unbounded: with EpisodeParams.coin_respawn the kernels continue any table by
+    that rule, so ONE row is the whole reference chain; longer tables are the finite chains of the
+    BASELINE configurations (coin_respawn=False)."""
     if not 1 <= n_coins <= MAX_COINS:
         raise ValueError(f"n_coins must be 1..{MAX_COINS}")
     k = np.arange(n_coins, dtype=np.float64)

@@ -39,7 +39,11 @@ class Population:
     def __init__(self, n: int, hidden: Iterable[int] = (10, 10), *, precision: str = "f32",
                  device: Optional[str] = None, sim: Optional[SimParams] = None,
                  episode: Optional[EpisodeParams] = None, coins: Optional[np.ndarray] = None,
-                 walls: Optional[np.ndarray] = None, init_state: Optional[Sequence[float]] = None):
+                 walls: Optional[np.ndarray] = None, init_state: Optional[Sequence[float]] = None,
+                 coin_respawn: Optional[bool] = None):
+        """coins=None is the reference's episode: the first coin (5, 5, 10) and the unbounded respawn
+        chain behind it (flight/__init__.py:25,47-52).  A coin table given explicitly is a finite chain
+        (nothing respawns after its last row) unless coin_respawn=True continues it by the reference rule."""
         torch = _torch()
         _native.require_gpu()
         if precision not in ("f32", "f64"):
@@ -52,10 +56,15 @@ class Population:
         self.dtype = torch.float32 if precision == "f32" else torch.float64
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.sim = sim if sim is not None else SimParams.reference()
-        coins = coin_chain_reference(MAX_COINS) if coins is None else np.ascontiguousarray(coins, np.float64).reshape(-1, COIN_STRIDE)
+        if coin_respawn is None:
+            coin_respawn = bool(episode.coin_respawn) if (episode is not None and coins is None) else coins is None
+        coins = coin_chain_reference(1) if coins is None else np.ascontiguousarray(coins, np.float64).reshape(-1, COIN_STRIDE)
+        if not 1 <= len(coins) <= MAX_COINS:
+            raise ValueError(f"need 1..{MAX_COINS} coin rows")
         walls = np.zeros((0, WALL_STRIDE)) if walls is None else np.ascontiguousarray(walls, np.float64).reshape(-1, WALL_STRIDE)
         self.episode = episode if episode is not None else EpisodeParams.reference()
         self.episode.n_coins, self.episode.n_walls = len(coins), len(walls)
+        self.episode.coin_respawn = int(bool(coin_respawn))
         self.coins_host, self.walls_host = coins, walls
         self.init_state = np.asarray(INITIAL_STATE if init_state is None else init_state, np.float64).reshape(12).copy()
 
@@ -194,6 +203,18 @@ class Population:
                                               self._ptr(self.genomes), self._ptr(self.fstate), self._ptr(self.istate),
                                               self.n, self._stream()), "ld_fly_step")
 
+    def steps(self, n_steps: int, waves_per_block: int = 0) -> None:
+        """`n_steps` iterations of fly()'s loop in ONE launch (ld_fly_steps_f32: float32, unrolled layer
+        specs), the 64 drones of a genome block served by `waves_per_block` wavefronts (0 = chosen from n).
+        Bit-identical to n_steps calls of step()."""
+        if self.precision != "f32":
+            raise ValueError("steps() is float32 (the float64 kernels take one launch per timestep)")
+        _native.check(_native.lib().ld_fly_steps_f32(C.byref(self.sim), C.byref(self.episode), C.byref(self.spec),
+                                                     self._ptr(self.coins_dev), self._ptr(self.walls_dev),
+                                                     self._ptr(self.genomes), self._ptr(self.fstate), self._ptr(self.istate),
+                                                     self.n, int(n_steps), int(waves_per_block), self._stream()),
+                      "ld_fly_steps_f32")
+
     def finalize(self) -> None:
         """Tail of fly(): distance penalty + result records (flight/__init__.py:83-87,97-99)."""
         if self._finalized:
@@ -212,12 +233,16 @@ class Population:
     RESIDENT_SPECS = ((8, 10), (10, 10), (16, 16), (32, 32), (64, 64, 64), (16,), (32,), (64,), (8, 8), (24, 24),
                       (48, 48), (64, 64), (32, 32, 32))
 
-    def fly(self, timesteps: int = 2500, engine: str = "step"):
+    def fly(self, timesteps: int = 2500, engine: str = "step", steps_per_launch: Optional[int] = None,
+            waves_per_block: int = 0):
         """fly(drone, timesteps) for every drone, enqueued from C on the current stream.  Returns the
         device tensor of result records ([n, 4] int32 view of ld_fitness_record); see results().
 
         engine="step": `timesteps` launches of the fused step kernel (one launch advances the whole
-        population one timestep; genes streamed from HBM every step) + finalize.
+        population one timestep; genes streamed from HBM every step) + finalize.  steps_per_launch /
+        waves_per_block (float32, unrolled specs) make the launch geometry explicit (ld_fly_rollout_steps_f32):
+        by default a block's 64 drones get as many wavefronts as fill the chip, and only shards too small
+        to amortise a kernel boundary take several timesteps per launch.
         engine="resident" (float32, specs RESIDENT_SPECS): one launch for the whole episode with the
         genome held in registers (ld_fly_rollout_resident_f32); bit-identical results, 3-6x faster.
         engine="auto": resident where available, else step."""
@@ -237,6 +262,13 @@ class Population:
             return self.records
         if engine != "step":
             raise ValueError("engine must be 'step' or 'resident'")
+        if steps_per_launch is not None or waves_per_block:
+            if self.precision != "f32":
+                raise ValueError("steps_per_launch / waves_per_block are float32 options")
+            args += [self.n, int(timesteps), int(steps_per_launch or 0), int(waves_per_block), self._stream()]
+            _native.check(_native.lib().ld_fly_rollout_steps_f32(*args), "ld_fly_rollout_steps_f32")
+            self._finalized = True
+            return self.records
         if self.precision == "f64":
             args.append(self._ptr(self.distance))
         args += [self.n, int(timesteps), self._stream()]

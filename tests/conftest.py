@@ -60,3 +60,13 @@ def g6():
 @pytest.fixture(scope="session")
 def g7():
     return load_golden("g7_flags.npz")
+
+
+@pytest.fixture
+def generic_kernels():
+    """generic_kernels(True) routes every layer spec to the run-time-spec kernels (ld_debug_force_generic);
+    the unrolled specialisations are back when the test ends."""
+    from learning_drones_amd import _native
+    lib = _native.lib()
+    yield lambda on: lib.ld_debug_force_generic(1 if on else 0)
+    lib.ld_debug_force_generic(0)

@@ -108,11 +108,8 @@ def test_one_step_wind_and_payload(Population, oracle, g1):
 # ------------------------------------------------------------------------------------------- controller
 @pytest.mark.parametrize("force_generic", [False, True])
 @pytest.mark.parametrize("precision", ["f32", "f64"])
-def test_mlp_forward(Population, g2, precision, force_generic, monkeypatch):
-    if force_generic:
-        monkeypatch.setenv("LD_FORCE_GENERIC", "1")
-    else:
-        monkeypatch.delenv("LD_FORCE_GENERIC", raising=False)
+def test_mlp_forward(Population, g2, precision, force_generic, generic_kernels):
+    generic_kernels(force_generic)
     for si in range(int(g2["n_specs"])):
         hidden = tuple(int(h) for h in g2[f"hidden_{si}"])
         x, ref = g2[f"x_{si}"], g2[f"y_{si}"]
@@ -129,7 +126,7 @@ def test_mlp_forward(Population, g2, precision, force_generic, monkeypatch):
             assert np.max(np.abs(y[:4] - ref[:4])) < 1e-3                # saturating rows
 
 
-def test_mlp_generic_equals_unrolled(Population, torch, monkeypatch):
+def test_mlp_generic_equals_unrolled(Population, torch, generic_kernels):
     rng = np.random.default_rng(3)
     for hidden in Population.RESIDENT_SPECS:
         n = 200                                                          # not a multiple of 64: tail lanes
@@ -138,10 +135,7 @@ def test_mlp_generic_equals_unrolled(Population, torch, monkeypatch):
         x = rng.normal(0, 3, (15, n))
         outs = []
         for generic in (False, True):
-            if generic:
-                monkeypatch.setenv("LD_FORCE_GENERIC", "1")
-            else:
-                monkeypatch.delenv("LD_FORCE_GENERIC", raising=False)
+            generic_kernels(generic)
             pop = Population(n, hidden)
             pop.set_genomes(genes)
             outs.append(pop.feed_forward(x).cpu().numpy())
@@ -318,8 +312,7 @@ def test_config2_one_coin(Population, oracle):
     pop.set_genomes(genes)
     pop.fly(T)
     got = pop.results()
-    ep = EpisodeParams.reference(n_coins=1)
-    ref = oracle.fly(pop.sim, ep, spec, genes, T, coins=coins, n_threads=min(oracle.max_threads(), 16))
+    ref = oracle.fly(pop.sim, pop.episode, spec, genes, T, coins=coins, n_threads=min(oracle.max_threads(), 16))
     assert got["coins"].max() == 1
     assert np.mean(got["reward"] == ref.reward) >= 0.995
 
@@ -448,6 +441,49 @@ def test_resident_engine_is_bit_identical(Population, torch, hidden, n, T):
         Population(4, (12,)).fly(10, engine="resident")       # no resident specialisation for this spec
 
 
+@pytest.mark.parametrize("hidden", [(32, 32), (16, 16), (10, 10), (8, 10), (64, 64, 64), (16,), (32,), (64,), (8, 8),
+                                    (24, 24), (48, 48), (64, 64), (32, 32, 32)])
+def test_split_waves_and_multistep_are_bit_identical(Population, torch, generic_kernels, hidden):
+    """ld_fly_steps_f32 (a genome block's 64 drones served by 1, 2, 4 or 8 wavefronts; several loop
+    iterations per launch) against one launch per timestep of the run-time-spec kernel, which shares no
+    code with it beyond the per-lane arithmetic: states, rewards, coins and flight times bit for bit, on
+    stable, marginal and crashing genomes, with a partial last block, coins collected and a wall hit."""
+    n, T = 200, 330
+    spec, genes, cls = _mixed_genomes(hidden, n, seed=5)
+    walls = np.array([[3.0, 3.0, 8.0, 4.5, 7.0, 12.0]])
+
+    def fresh():
+        pop = Population(n, hidden, walls=walls, coins=coin_chain_reference(2))
+        pop.set_genomes(genes)
+        return pop
+
+    generic_kernels(True)
+    ref = fresh()
+    for _ in range(T):
+        ref.step()
+    generic_kernels(False)
+    crashed = (ref.istate[2] & 1).bool()
+    assert crashed.any() and not crashed.all() and int(ref.istate[1].max()) >= 1
+    for waves in (0, 1, 2, 4, 8):
+        for k in (1, 7, T):
+            if k == 1 and waves in (2, 4) and hidden != (32, 32):
+                continue                                          # keep the run time down: every (waves, k) pair on 32-32
+            pop = fresh()
+            done = 0
+            while done < T:
+                pop.steps(min(k, T - done), waves)
+                done += min(k, T - done)
+            assert torch.equal(pop.fstate, ref.fstate), (hidden, waves, k)
+            assert torch.equal(pop.istate, ref.istate), (hidden, waves, k)
+    pop = fresh()                                                 # the default rollout entry point takes the same kernels
+    pop.fly(T)
+    ref.finalize()
+    assert torch.equal(pop.records, ref.records) and torch.equal(pop.fstate, ref.fstate)
+    pop = fresh()
+    pop.fly(T, steps_per_launch=16, waves_per_block=4)
+    assert torch.equal(pop.records, ref.records)
+
+
 def test_full_size_config5_shard(Population, torch):
     """One GPU's share of BASELINE config 5: 131 072 drones x 4 000 steps, 15-64-64-64-4 controller
     (5.0 GB of genes), 5-coin chain and wall boxes.  Size-independent properties: genomes replicated
@@ -521,9 +557,9 @@ def test_limit_specs_and_tables(Population, oracle, hidden):
     genes = genes.astype(np.float32).astype(np.float64)
     walls = np.array([[20.0 + 3 * k, -50.0, 0.0, 21.0 + 3 * k, 50.0, 80.0] for k in range(15)] + [[-2, -2, 14, 2, 2, 15.0]])
     coins = coin_chain_reference(64)
-    ep = EpisodeParams.reference(n_coins=64, n_walls=16)
     threads = min(oracle.max_threads(), 16)
     pop = Population(n, hidden, precision="f64", coins=coins, walls=walls)
+    ep = pop.episode
     pop.set_genomes(genes)
     pop.fly(T)
     got = pop.results()

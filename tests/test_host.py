@@ -26,7 +26,7 @@ def test_header_and_library_agree(lib):
     assert declared == set(_native.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ld_version() == 1
+    assert lib.ld_version() == _native.ABI_VERSION == 2
     assert b"spec" in lib.ld_strerror(-2)
 
 
@@ -60,7 +60,7 @@ def test_host_side_entry_points(lib):
 
 def test_struct_layouts_match_header():
     assert C.sizeof(SimParams) == 16 * 8
-    assert C.sizeof(EpisodeParams) == 4 * 4 + 4 * 8 + 2 * 4
+    assert C.sizeof(EpisodeParams) == 4 * 4 + 4 * 8 + 4 * 4
     assert C.sizeof(MlpSpec) == 5 * 4
     assert C.sizeof(params.FitnessRecord) == 16 == params.FITNESS_DTYPE.itemsize
 

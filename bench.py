@@ -7,12 +7,18 @@
 
 Workload (BASELINE config 3, the one the metric is quoted on): 65 536 drones per GPU x 2 000
 timesteps, 15-32-32-4 controller, 3-coin chain, crash penalty on, float32.  A "step" is one whole
-episode of the population = 2 000 launches of the fused step kernel + the finalize launch (+ the
-RCCL all-gather of the 16-byte fitness records when N > 1).  Population shards are independent, so
-scaling is weak: every rank owns 65 536 drones.  Genomes are synthetic: hover controllers
-(learning-drones_amd/controllers.py) with small per-drone noise, so that nearly every drone is
-alive for all 2 000 steps and every counted drone-step does the full work (frozen wavefronts skip
-their gene traffic; the JSON line reports the live fraction).
+episode of the population = the fused-step launches of ld_fly_rollout_f32 (16 timesteps per launch, the
+drone state in registers in between: 125 launches) + the finalize launch (+ the RCCL all-gather of the
+16-byte fitness records when N > 1).  Population shards are independent, so the headline line is weak
+scaling: every rank owns 65 536 drones.  With N > 1 the same run ALSO times the strong-scaling case
+BASELINE's target describes (ONE 65 536-drone population split over the N GPUs) and reports it in the
+`strong_scaling` object of the same JSON line, together with `ranks_seen` and a checksum of the gathered
+records, so that the line proves the collective saw N ranks.  `--strong` makes the strong case the
+headline instead.
+
+Genomes are synthetic: hover controllers (learning-drones_amd/controllers.py) with small per-drone
+noise, so that nearly every drone is alive for all 2 000 steps and every counted drone-step does the
+full work (frozen blocks skip their gene traffic; the JSON line reports the live fraction).
 
 Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events on the launch stream,
 `cpu_baseline` times the CPU oracle (the stand-in for the reference's Python loop) on the host
@@ -47,9 +53,20 @@ def make_genomes(torch, n, hidden, device, seed):
     return base + 2e-4 * torch.randn(base.shape, generator=g, device=device, dtype=torch.float32)
 
 
+def cpu_model() -> str:
+    try:
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(hidden, n_coins, timesteps):
     """The oracle (CPU restatement of the reference loop, float64 with the reference's rounding
-    points) on all host cores, on a bounded sample of the same workload."""
+    points) on one host thread and on all of this GPU's host cores, on bounded samples of the same
+    workload (~4 s + ~12 s of wall time)."""
     from learning_drones_amd import controllers
     from learning_drones_amd.params import EpisodeParams, MlpSpec, SimParams, coin_chain_reference
     from oracle import oracle as O
@@ -58,18 +75,24 @@ def cpu_baseline(hidden, n_coins, timesteps):
     spec = MlpSpec.from_hidden(hidden)
     base = np.concatenate([w.ravel() for w in controllers.hover_net(hidden)])
     rng = np.random.default_rng(0)
-    sim, ep, coins = SimParams.reference(), EpisodeParams.reference(n_coins=n_coins), coin_chain_reference(n_coins)
-    probe = base[None, :] + rng.normal(0, 2e-4, (64 * cores, spec.param_count))
-    t0 = time.perf_counter()
-    O.fly(sim, ep, spec, probe, 200, coins=coins, n_threads=cores)
-    rate = len(probe) * 200 / (time.perf_counter() - t0)
-    n = int(min(65536, max(256, rate * 12.0 / timesteps)))           # ~12 s of wall time
-    genes = base[None, :] + rng.normal(0, 2e-4, (n, spec.param_count))
-    t0 = time.perf_counter()
-    O.fly(sim, ep, spec, genes, timesteps, coins=coins, n_threads=cores)
-    dt = time.perf_counter() - t0
-    return {"value": n * timesteps / dt, "unit": "drone-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} drones x {timesteps} steps, same controller/coins, float64 oracle, {dt:.1f} s"}
+    sim, coins = SimParams.reference(), coin_chain_reference(n_coins)
+    ep = EpisodeParams.reference(n_coins=n_coins, coin_respawn=False)
+
+    def timed(n, T, threads):
+        genes = base[None, :] + rng.normal(0, 2e-4, (n, spec.param_count))
+        t0 = time.perf_counter()
+        O.fly(sim, ep, spec, genes, T, coins=coins, n_threads=threads)
+        return n * T / (time.perf_counter() - t0), time.perf_counter() - t0
+
+    rate1, _ = timed(16, 200, 1)                                        # probes, to size the samples
+    n1 = int(min(4096, max(8, rate1 * 4.0 / timesteps)))
+    one, dt1 = timed(n1, timesteps, 1)
+    rate, _ = timed(64 * cores, 200, cores)
+    n = int(min(65536, max(256, rate * 12.0 / timesteps)))
+    value, dt = timed(n, timesteps, cores)
+    return {"value": value, "unit": "drone-steps/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "sample": f"{n} drones x {timesteps} steps, same controller/coins, float64 oracle, {cores} threads, {dt:.1f} s",
+            "one_thread": {"value": one, "cores": 1, "sample": f"{n1} drones x {timesteps} steps, {dt1:.1f} s"}}
 
 
 def main():
@@ -77,16 +100,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--drones", type=int, default=WORKLOAD["drones_per_gpu"], help="drones per GPU")
+    ap.add_argument("--drones", type=int, default=WORKLOAD["drones_per_gpu"],
+                    help="drones per GPU (weak scaling); with --strong, and for the strong_scaling object, the TOTAL population")
     ap.add_argument("--timesteps", type=int, default=WORKLOAD["timesteps"])
     ap.add_argument("--hidden", type=str, default=",".join(map(str, WORKLOAD["hidden"])))
     ap.add_argument("--coins", type=int, default=WORKLOAD["n_coins"])
-    ap.add_argument("--strong", action="store_true", help="strong scaling: --drones is the TOTAL population, split over the "
-                    "ranks (BASELINE's 8-GPU target is quoted for a 65 536-drone population in all); default is weak "
-                    "scaling with --drones per GPU")
+    ap.add_argument("--strong", action="store_true", help="make the strong-scaling case the headline: --drones is the TOTAL "
+                    "population, split over the ranks (BASELINE's 8-GPU target is quoted for a 65 536-drone population in all)")
+    ap.add_argument("--steps-per-launch", type=int, default=0, help="timesteps per fused launch (0 = the library's choice)")
+    ap.add_argument("--waves-per-block", type=int, default=0, help="wavefronts per 64-drone genome block (0 = the library's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline rollout and its roofline (for rocprofv3 "
-                    "runs: keeps every fly_step_kernel launch in the trace a full, live-population launch)")
+                    "runs: keeps every fused launch in the trace a full, live-population launch of the headline geometry)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets several ranks share one "
                     "GPU to rehearse the N > 1 control flow on a one-GPU box")
     args = ap.parse_args()
@@ -115,80 +140,139 @@ def main():
     from learning_drones_amd.parallel import ShardedPopulation
     from learning_drones_amd.params import coin_chain_reference
     hidden = tuple(int(h) for h in args.hidden.split(","))
-    if args.strong and args.drones % world:
-        raise SystemExit("--strong needs --drones divisible by the number of GPUs")
-    n_local, T = (args.drones // world if args.strong else args.drones), args.timesteps
-    pop = ShardedPopulation(n_local * world, hidden, coins=coin_chain_reference(args.coins), precision="f32",
-                            device=device, process_group=dist.group.WORLD if dist else None)
-    assert pop.local.n == n_local
-    pop.local.set_genomes(make_genomes(torch, n_local, hidden, device, seed=rank))
-
-    def episode():
-        pop.local.reset()
-        return pop.fly(T)                      # T step launches + finalize (+ all-gather of records)
+    T = args.timesteps
+    if args.drones % world and (args.strong or world > 1):
+        raise SystemExit("--drones must be divisible by the number of GPUs (strong-scaling split)")
 
     def fence():
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        episode()
-    fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()                               # HIP events on the launch stream, over the timed region
-    for _ in range(args.steps):
-        records = episode()
-    ev1.record()
-    fence()
-    dt = time.perf_counter() - t0
-    timed_launch_ms = ev0.elapsed_time(ev1) / (args.steps * T)      # per fly_step_kernel launch
+    def max_over_ranks(seconds):
+        if not dist:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def fly_kwargs():
+        if args.steps_per_launch or args.waves_per_block:
+            return dict(steps_per_launch=args.steps_per_launch or None, waves_per_block=args.waves_per_block)
+        return {}
+
+    def measure(n_local, steps, warmup):
+        """`steps` timed episodes of a population of n_local drones per rank: barrier + synchronize on both
+        sides, wall time = max over ranks; the fused launches' average duration from HIP events on the
+        launch stream over the same region."""
+        pop = ShardedPopulation(n_local * world, hidden, coins=coin_chain_reference(args.coins), precision="f32",
+                                device=device, process_group=dist.group.WORLD if dist else None)
+        assert pop.local.n == n_local
+        pop.local.set_genomes(make_genomes(torch, n_local, hidden, device, seed=rank))
+        geo = pop.local.rollout_geometry(T)
+        if args.steps_per_launch:
+            geo["steps_per_launch"] = args.steps_per_launch
+            geo["launches"] = -(-T // args.steps_per_launch)
+        if args.waves_per_block:
+            geo["waves_per_block"] = args.waves_per_block
+
+        def episode():
+            pop.local.reset()
+            return pop.fly(T, **fly_kwargs())          # fused launches + finalize (+ all-gather of records)
+
+        for _ in range(warmup):
+            episode()
+        fence()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()                                   # HIP events on the launch stream, over the timed region
+        records = None
+        for _ in range(steps):
+            records = episode()
+        ev1.record()
+        fence()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        launch_ms = ev0.elapsed_time(ev1) / (steps * geo["launches"]) if steps else float("nan")
+        bytes_per_launch = pop.local.bytes_per_launch(geo["steps_per_launch"])
+        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "kernel": "fly_split_kernel<float, L=%d, %s>" % (geo["waves_per_block"], "-".join(map(str, hidden))),
+                "bytes_per_launch": bytes_per_launch, "launch_us": launch_ms * 1e3,
+                "timesteps_per_launch": geo["steps_per_launch"], "wavefronts_per_block": geo["waves_per_block"],
+                "launches_per_episode": geo["launches"],
+                "bytes_model": "n * (timesteps_per_launch * 4P + 200): genes once per timestep, the 25 state words read and "
+                               "written once per launch (they stay in registers in between); 4P + 200 per drone-step at 1"}
+        return pop, records, dt, roof
+
+    n_total_strong = args.drones
+    n_local = args.drones // world if args.strong else args.drones
+    pop, records, dt, roof = measure(n_local, args.steps, args.warmup)
+
+    # proof that the collective saw every rank: the ranks themselves, gathered, and a checksum of the
+    # gathered records (identical on every rank by construction; rank 0 prints it)
+    ranks_seen = [0]
     if dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        seen = torch.empty((world,), dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(seen, torch.tensor([rank], dtype=torch.int64, device=device))
+        ranks_seen = [int(r) for r in seen.tolist()]
+
+    def checksum(rec):
+        w = torch.tensor([1, 3, 5, 7], dtype=torch.int64, device=rec.device)
+        idx = torch.arange(rec.shape[0], dtype=torch.int64, device=rec.device) % 1021 + 1
+        return int(((rec.to(torch.int64) * w).sum(dim=1) * idx).sum().item() % (2 ** 61 - 1))
 
     # live fraction: flight_time / T over the whole population (records are gathered on every rank)
-    flight = records[:, 1].double()
-    live = float(flight.sum().item()) / (records.shape[0] * T)
+    live = float(records[:, 1].double().sum().item()) / (records.shape[0] * T)
+    out_records = {"rows": int(records.shape[0]), "checksum": checksum(records)}
 
-    # Roofline of the dominant kernel (fly_step_kernel): algorithmic bytes per launch over the average
-    # launch duration of the timed region (HIP events above; the per-episode reset / finalize / gather
-    # are inside that interval, so it is slightly conservative).  An isolated run of 400 consecutive
-    # launches is reported next to it.
-    roof_launches = 400
-    pop.local.reset()
-    for _ in range(20):
-        pop.local.step()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(roof_launches):
-        pop.local.step()
-    e1.record()
-    torch.cuda.synchronize()
-    isolated_launch_ms = e0.elapsed_time(e1) / roof_launches
-    launch_ms = timed_launch_ms
-    bytes_per_launch = pop.local.bytes_per_drone_step * n_local
-    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+    # ---- the strong-scaling case in the same run (N > 1): ONE population of --drones in all
+    strong = None
+    if world > 1 and not args.strong and not args.no_extras:
+        pop_s, rec_s, dt_s, roof_s = measure(n_total_strong // world, args.steps, 1)
+        strong = {"value": n_total_strong * T * args.steps / dt_s, "unit": "drone-steps/s", "scaling": "strong",
+                  "population": n_total_strong, "drones_per_gpu": n_total_strong // world, "ms_per_step": dt_s / args.steps * 1e3,
+                  "roofline": roof_s, "records": {"rows": int(rec_s.shape[0]), "checksum": checksum(rec_s)}}
+        del pop_s
 
-    # Practical ceiling next to the spec peak: a device-to-device copy of 1 GiB on this
-    # GPU, read + write bytes over the event-timed duration.
-    src_buf = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=device).normal_()
-    dst_buf = torch.empty_like(src_buf)
-    for _ in range(3):
-        dst_buf.copy_(src_buf)
-    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    c0.record()
-    for _ in range(10):
-        dst_buf.copy_(src_buf)
-    c1.record()
-    torch.cuda.synchronize()
-    copy_gbs = 10 * 2 * src_buf.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
-    del src_buf, dst_buf
+    extras = {}
+    if not args.no_extras:
+        # one timestep per launch (the literal contract: one launch advances the population one timestep)
+        pop.local.reset()
+        for _ in range(20):
+            pop.local.step()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(400):
+            pop.local.step()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 400 * 1e3
+        extras["one_timestep_per_launch"] = {"launch_us": us, "achieved": pop.local.bytes_per_launch(1) / us / 1e3, "unit": "GB/s",
+                                             "frac": pop.local.bytes_per_launch(1) / us / 1e3 / HBM_PEAK_GBS,
+                                             "bytes_per_launch": pop.local.bytes_per_launch(1)}
+        # Practical ceiling next to the spec peak (SURVEY 8d): a device-to-device copy of 1 GiB on this GPU
+        src_buf = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=device).normal_()
+        dst_buf = torch.empty_like(src_buf)
+        for _ in range(3):
+            dst_buf.copy_(src_buf)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(10):
+            dst_buf.copy_(src_buf)
+        c1.record()
+        torch.cuda.synchronize()
+        roof["copy_ceiling_gbs"] = 10 * 2 * src_buf.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del src_buf, dst_buf
+
+    # The shard one GPU owns when BASELINE's 65 536-drone population is spread over 8 (N = 1 only: with
+    # N > 1 the strong_scaling object measures the real thing)
+    if world == 1 and not args.no_extras and n_local == WORKLOAD["drones_per_gpu"]:
+        _, _, dt_8, roof_8 = measure(n_local // 8, args.steps, 1)
+        extras["shard_of_8"] = {"drones": n_local // 8, "value": n_local // 8 * T * args.steps / dt_8, "unit": "drone-steps/s",
+                                "ms_per_step": dt_8 / args.steps * 1e3, "roofline": roof_8}
 
     # The reference's own kind of population (random genomes, evolve/brain.py:24): every drone tumbles
-    # and crashes within a few hundred steps; frozen wavefronts skip their gene traffic, so an episode
+    # and crashes within a few hundred steps; frozen blocks skip their gene traffic, so an episode
     # costs far less than N*T full drone-steps.  Informational (live drone-steps only are real work).
     random_pop = {}
     engines = () if args.no_extras else (("step", "resident") if hidden in pop.local.RESIDENT_SPECS else ("step",))
@@ -205,18 +289,24 @@ def main():
         random_pop["live_drone_step_fraction"] = float(rec[:, 1].double().sum().item()) / (rec.shape[0] * T)
         pop.local.set_genomes(make_genomes(torch, n_local, hidden, device, seed=rank))
 
-    # HBM bytes per launch from the PMC counters: collected by separate rocprofv3 --pmc passes of this
-    # same command and committed under profiles/ (they cannot be read live); used only when the
-    # profiled launch configuration is the one being run.
-    traffic, traffic_src = None, None
+    # HBM bytes per launch from the PMC counters and the profiled launch duration: collected by separate
+    # rocprofv3 passes of this same command and committed under profiles/ (they cannot be read live);
+    # used only when the profiled launch configuration is the one being run.
     for f in sorted((REPO / "profiles").glob("r*_fly_step_pmc.json"), reverse=True):
         prof = json.loads(f.read_text())
-        if prof["config"]["drones"] == n_local and tuple(prof["config"]["hidden"]) == hidden and prof["config"]["coins"] == args.coins:
-            traffic, traffic_src = prof["hbm_traffic_bytes_per_launch"], f"profiles/{f.name}"
+        cfg = prof["config"]
+        if (cfg["drones"] == n_local and tuple(cfg["hidden"]) == hidden and cfg["coins"] == args.coins
+                and cfg.get("timesteps_per_launch", 1) == roof["timesteps_per_launch"]
+                and cfg.get("wavefronts_per_block", 1) == roof["wavefronts_per_block"]):
+            roof["traffic"], roof["traffic_source"] = prof["hbm_traffic_bytes_per_launch"], f"profiles/{f.name}"
+            if prof.get("launch_us_profiled"):
+                roof["launch_us_profiled"] = prof["launch_us_profiled"]
+                roof["frac_profiled"] = roof["bytes_per_launch"] / prof["launch_us_profiled"] / 1e3 / HBM_PEAK_GBS
             break
+    roof.setdefault("traffic", None)
 
     # The genome-resident engine (one launch per episode, genes held in registers: beyond the contract
-    # of "one launch per timestep", bit-identical results) on the same workload, for reference.
+    # of streaming the genes every timestep, bit-identical results) on the same workload, for reference.
     resident = None
     if hidden in pop.local.RESIDENT_SPECS and not args.no_extras:
         pop.local.reset()
@@ -227,43 +317,43 @@ def main():
             pop.local.reset()
             pop.fly(T, engine="resident")
         fence()
-        rdt = time.perf_counter() - r0
-        if dist:
-            tmax = torch.tensor([rdt], dtype=torch.float64, device=device)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            rdt = float(tmax.item())
+        rdt = max_over_ranks(time.perf_counter() - r0)
         resident = {"value": n_local * world * T * args.steps / rdt, "unit": "drone-steps/s", "ms_per_step": rdt / args.steps * 1e3,
                     "speedup_over_step_engine": dt / rdt,
                     "note": "ld_fly_rollout_resident_f32: whole episode in one launch, genome in VGPRs (VALU-bound, "
                             "HBM traffic ~1/T of the step engine); not the kernel the roofline object describes"}
 
     # generations/s of the whole loop on the device: rollout + all-gather of records + argmax/elite +
-    # all-gather of genome shards (N > 1) + select/breed kernels + state reset.  Mutated children of
-    # stable flyers crash early and frozen wavefronts skip their gene traffic, so this is faster than
-    # 1 / episode time; the live fraction of the measured generations is reported next to it.
+    # parent exchange (N > 1) + select/breed kernels + state reset.  Mutated children of stable flyers
+    # crash early and frozen blocks skip their gene traffic, so this is faster than 1 / episode time; the
+    # live fraction of the measured generations is reported next to it.
     from learning_drones_amd.parallel import DeviceEvolution
     evo = DeviceEvolution(pop, seed=0x1D20)
     n_gen, gen_live, gen_dt, gen_error = 3, 0.0, float("nan"), ("skipped (--no-extras)" if args.no_extras else None)
-    try:
-        if args.no_extras:
-            raise StopIteration
-        pop.local.reset()
-        evo.step(T)
-        fence()
-        g0 = time.perf_counter()
-        for _ in range(n_gen):
-            _, _, rec = evo.step(T)
-            gen_live += float(rec[:, 1].double().sum().item()) / (rec.shape[0] * T) / n_gen
-        fence()
-        gen_dt = time.perf_counter() - g0
+    if not args.no_extras:
+        ok = 1
+        try:
+            pop.local.reset()
+            evo.step(T)
+            fence()
+            g0 = time.perf_counter()
+            for _ in range(n_gen):
+                _, _, rec = evo.step(T)
+                gen_live += float(rec[:, 1].double().sum().item()) / (rec.shape[0] * T) / n_gen
+            fence()
+            gen_dt = max_over_ranks(time.perf_counter() - g0)
+        except RuntimeError as err:      # reported, and fatal for the whole job below (no rank may carry on alone)
+            gen_error, ok = str(err)[:200], 0
         if dist:
-            tmax = torch.tensor([gen_dt], dtype=torch.float64, device=device)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            gen_dt = float(tmax.item())
-    except StopIteration:
-        pass
-    except RuntimeError as err:          # e.g. a backend without the collectives the generation step uses
-        gen_error = str(err)[:200]
+            flag = torch.tensor([ok], dtype=torch.int64, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if rank == 0:
+                    print(json.dumps({"error": "generation step failed on at least one rank", "detail": gen_error}), flush=True)
+                dist.destroy_process_group()
+                raise SystemExit(3)
+        elif not ok:
+            raise SystemExit(f"generation step failed: {gen_error}")
     # the generation step's own kernels (select + breed, no communication): local shard bred from itself
     from learning_drones_amd.params import GaParams
     breed_ms = breed_gbs = None
@@ -281,6 +371,7 @@ def main():
 
     known = {(65536, 2000, (32, 32), 3): "BASELINE config 3", (1024, 2000, (16, 16), 1): "BASELINE config 2",
              (32768, 4000, (32, 32), 3): "BASELINE config 4 (one GPU's shard)",
+             (8192, 2000, (32, 32), 3): "BASELINE target population (65 536 drones) spread over 8 GPUs: one GPU's shard",
              (131072, 4000, (64, 64, 64), 5): "BASELINE config 5 (one GPU's shard, no walls)"}
     config_name = known.get((n_local, T, hidden, args.coins), "custom workload")
 
@@ -294,29 +385,27 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{config_name}: {n_local} drones/GPU x {T} timesteps, 15-{'-'.join(map(str, hidden))}-4 "
                                    f"controller per drone, {args.coins}-coin chain, crash penalty; step = one episode "
-                                   f"({T} fused-step launches + finalize" + (" + RCCL all-gather of fitness records)" if world > 1 else ")"),
+                                   f"({roof['launches_per_episode']} fused launches of {roof['timesteps_per_launch']} timesteps + finalize"
+                                   + (" + RCCL all-gather of fitness records)" if world > 1 else ")"),
                        "population": n_total, "timesteps": T, "hidden": list(hidden), "coins": args.coins,
                        "parallelism": f"population sharded x{world}, no data-path collective inside the rollout"},
+            "ranks_seen": ranks_seen, "records": out_records,
+            "strong_scaling": strong,
             "evaluations_per_s": args.steps / dt,
             "live_drone_step_fraction": live,
             "resident_engine": resident,
             "random_init_population": random_pop,
             "generations_per_s": None if gen_error else n_gen / gen_dt,
-            "generation": {"measured": n_gen, "includes": "rollout, record all-gather, elite, genome all-gather (N>1), "
+            "generation": {"measured": n_gen, "includes": "rollout, record all-gather, elite, parent exchange (N>1), "
                            "device select+breed (evolve/util.py + Drone.mutate semantics), reset; rollout engine: "
                            + evo.engine + ", parent exchange: " + (evo.exchange if world > 1 else "local"),
                            "live_drone_step_fraction": gen_live, "error": gen_error,
                            "select_breed_ms": breed_ms, "select_breed_gbs": breed_gbs,
                            "select_breed_note": "gather of 16-byte parent words at random drone indices + streaming "
                                                 "child stores; algorithmic 8P bytes per drone"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "copy_ceiling_gbs": copy_gbs,
-                         "kernel": "fly_step_kernel<float, UnrolledNet<32,32>>" if hidden == (32, 32) else "fly_step_kernel",
-                         "bytes_per_launch": bytes_per_launch, "launch_us": launch_ms * 1e3,
-                         "launch_us_isolated": isolated_launch_ms * 1e3,
-                         "bytes_per_drone_step": pop.local.bytes_per_drone_step},
+            "roofline": roof,
         }
+        out.update(extras)
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline(hidden, args.coins, T)
         print(json.dumps(out), flush=True)

@@ -14,7 +14,8 @@
  *     copied; no C++/torch types, no exceptions across the boundary.
  *   - Every array pointer is a DEVICE pointer owned by the caller (e.g. a
  *     PyTorch-ROCm tensor's data_ptr()); the library allocates nothing and
- *     keeps no global state.  Structs live in HOST memory.
+ *     keeps no global state (the ld_debug_* test hook aside).  Structs live in
+ *     HOST memory.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *     Kernels are enqueued and NOT synchronised; functions are re-entrant.
  *     One population must not be stepped from two streams at once.
@@ -228,17 +229,17 @@ int ld_fly_step_f64(const ld_sim_params *sim, const ld_episode_params *ep, const
                     double *fstate, int32_t *istate, int64_t n, void *stream);
 
 /* `n_steps` iterations of that loop body in ONE launch (float32, layer specs with an unrolled
- * specialisation; others return LD_ERR_SPEC), and the launch geometry made explicit:
- * the 64 drones of a genome block are served by `waves_per_block` wavefronts of one workgroup (1, 2,
- * 4 or 8; 0 = chosen from n so that the grid has at least one wavefront per SIMD).  Each wavefront
- * streams a contiguous share of every layer's rows (still one lane per drone, one coalesced 1 KiB
- * line per gene word, every neuron's sum in gene order), the layers' outputs cross wavefronts through
- * LDS.  Small shards need this to fill the chip: 8 192 drones are 128 wavefronts at one lane per
- * drone and one wavefront per block.  With n_steps > 1 the state stays in registers between steps
- * and the genes are re-read every step (from L2 / Infinity Cache when the shard's genomes fit): the
- * per-step launch boundary disappears, which is what bounds populations of a few thousand drones.
- * Results are bit-identical to n_steps calls of ld_fly_step_f32 for every waves_per_block.
- * ld_fly_step_f32 itself is ld_fly_steps_f32(..., 1, 0, stream) for those specs. */
+ * specialisation; others return LD_ERR_SPEC), with the launch geometry made explicit: the 64 drones
+ * of a genome block are served by `waves_per_block` wavefronts of one workgroup (1, 2, 4 or 8; 0 =
+ * chosen from n, the spec and n_steps).  Each wavefront streams a contiguous share of every layer's
+ * rows (still one lane per drone, one coalesced 1 KiB line per gene word, every neuron's sum in gene
+ * order), the layers' outputs cross wavefronts through LDS.  Small shards need this to fill the
+ * chip: 8 192 drones are 128 wavefronts at one wavefront per block.  With n_steps > 1 the drone
+ * state stays in registers between timesteps and the genes are re-streamed every step (from L2 /
+ * Infinity Cache when the shard's genomes fit there): no per-step kernel boundary and 200/n_steps
+ * instead of 200 bytes of state traffic per drone-step.  Results are bit-identical to n_steps calls
+ * of ld_fly_step_f32 for every waves_per_block.  ld_fly_step_f32 itself is
+ * ld_fly_steps_f32(..., 1, 0, stream) for those specs. */
 int ld_fly_steps_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
                      const double *coins, const double *walls, const float *genomes,
                      float *fstate, int32_t *istate, int64_t n, int32_t n_steps, int32_t waves_per_block,
@@ -253,8 +254,11 @@ int ld_fly_finalize_f64(const ld_episode_params *ep, const double *coins, const 
                         int32_t *istate, ld_fitness_record *records, double *distance_f64,
                         int64_t n, void *stream);
 
-/* fly(drone, timesteps) for the whole population: `timesteps` fused-step launches followed by
- * the finalize launch, all enqueued on `stream` from C (no per-step host round trip). */
+/* fly(drone, timesteps) for the whole population: the fused-step launches followed by the finalize
+ * launch, all enqueued on `stream` from C (no per-step host round trip).  _f64 and the float32 specs
+ * without an unrolled specialisation take one launch per timestep; the unrolled float32 specs take
+ * ld_fly_rollout_steps_f32's default geometry (several timesteps per launch, state in registers in
+ * between; identical results). */
 int ld_fly_rollout_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
                        const double *coins, const double *walls, const float *genomes,
                        float *fstate, int32_t *istate, ld_fitness_record *records,
@@ -264,14 +268,22 @@ int ld_fly_rollout_f64(const ld_sim_params *sim, const ld_episode_params *ep, co
                        double *fstate, int32_t *istate, ld_fitness_record *records,
                        double *distance_f64, int64_t n, int32_t timesteps, void *stream);
 
-/* As ld_fly_rollout_f32 with `steps_per_launch` loop iterations per launch (ld_fly_steps_f32;
- * 1 = one launch per timestep, 0 = chosen from n and the spec: 1 unless the shard is small enough
- * to be bound by the launch boundary) and `waves_per_block` as in ld_fly_steps_f32. */
+/* As ld_fly_rollout_f32 with the launch geometry explicit: `steps_per_launch` loop iterations per
+ * launch (ld_fly_steps_f32; 1 = one launch per timestep, 0 = the library's choice, 16) and
+ * `waves_per_block` as in ld_fly_steps_f32.  ld_fly_rollout_f32 is this with (0, 0) for the specs that
+ * have an unrolled specialisation; LD_ERR_SPEC for the others. */
 int ld_fly_rollout_steps_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
                              const double *coins, const double *walls, const float *genomes,
                              float *fstate, int32_t *istate, ld_fitness_record *records,
                              int64_t n, int32_t timesteps, int32_t steps_per_launch, int32_t waves_per_block,
                              void *stream);
+
+/* What ld_fly_rollout_f32 / ld_fly_rollout_steps_f32(..., 0, 0) will launch for this spec and shard size
+ * (for reporting: a benchmark states the geometry it measured): loop iterations per launch, wavefronts
+ * per genome block, and the number of fused-step launches of a `timesteps`-step episode.  Specs without an
+ * unrolled specialisation: 1, 1, timesteps. */
+int ld_fly_rollout_geometry_f32(const ld_mlp_spec *spec, int64_t n, int32_t timesteps,
+                                int32_t *steps_per_launch, int32_t *waves_per_block, int32_t *n_launches);
 
 /* fly(drone, timesteps) with the genome RESIDENT in registers for the whole episode (float32):
  * ONE launch runs all `timesteps` iterations; each drone owns L lanes of a wavefront that share its

@@ -26,7 +26,7 @@ EXPORTS = (
     "ld_fly_finalize_f32", "ld_fly_finalize_f64", "ld_fly_rollout_f32", "ld_fly_rollout_f64",
     "ld_ga_select", "ld_ga_breed_f32", "ld_ga_breed_f64", "ld_pid_episode_f32", "ld_pid_episode_f64",
     "ld_fly_rollout_resident_f32", "ld_debug_force_generic", "ld_accelerations_f32", "ld_accelerations_f64",
-    "ld_fly_steps_f32", "ld_fly_rollout_steps_f32",
+    "ld_fly_steps_f32", "ld_fly_rollout_steps_f32", "ld_fly_rollout_geometry_f32",
 )
 ABI_VERSION = 2
 
@@ -98,6 +98,8 @@ def _declare(h: C.CDLL) -> None:
     h.ld_accelerations_f32.argtypes = [sim, vp, vp, vp, vp, i64, vp]
     h.ld_accelerations_f64.argtypes = [sim, vp, vp, vp, vp, i64, vp]
     h.ld_debug_force_generic.argtypes = [C.c_int]
+    pi32 = C.POINTER(C.c_int32)
+    h.ld_fly_rollout_geometry_f32.argtypes = [spec, i64, i32, pi32, pi32, pi32]
     ga = C.POINTER(GaParams)
     h.ld_ga_select.argtypes = [ga, spec, vp, i64, i64, i64, vp, vp, vp]
     h.ld_ga_breed_f32.argtypes = [ga, spec, vp, i64, i32, vp, vp, vp, i64, i64, vp, vp]

@@ -8,11 +8,8 @@
 #include "ld_pid.hpp"
 #include "ld_split.hpp"
 
-#ifndef LD_MULTISTEP_MAX_BYTES
-#define LD_MULTISTEP_MAX_BYTES (8 << 20)
-#endif
-#ifndef LD_MULTISTEP_STEPS
-#define LD_MULTISTEP_STEPS 16
+#ifndef LD_STEPS_PER_LAUNCH
+#define LD_STEPS_PER_LAUNCH 16
 #endif
 
 int ld_resident_dispatch(const ld_sim_params*, const ld_episode_params*, const ld_mlp_spec*, const double*, const double*,
@@ -49,21 +46,21 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 
 template <int... H> bool spec_is(const ld_mlp_spec& s) { return ld::NetShape<H...>::matches(s); }
 
+// The one-wavefront-per-block fused step: float64 (every spec; unrolled where there is a specialisation) and
+// the float32 specs WITHOUT an unrolled specialisation.  Unrolled float32 specs take dispatch_split_f32.
 template <typename Real, bool Faithful>
 int dispatch_fly_step(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,
                       const double* coins, const double* walls, const Real* genomes, Real* fstate,
                       int32_t* istate, int64_t n, hipStream_t stream)
 {
-    if (!g_force_generic.load(std::memory_order_relaxed)) {
+    if constexpr (sizeof(Real) == 8) {
+        if (!g_force_generic.load(std::memory_order_relaxed)) {
 #define X(TAG, ...)                                                                                          \
-        if (spec_is<__VA_ARGS__>(*spec)) {                                                                   \
-            if constexpr (sizeof(Real) == 4)                                                                 \
-                return ld_u_fly_f32_##TAG(sim, ep, spec, coins, walls, genomes, fstate, istate, n, stream);  \
-            else                                                                                             \
-                return ld_u_fly_f64_##TAG(sim, ep, spec, coins, walls, genomes, fstate, istate, n, stream);  \
-        }
-        LD_FOR_EACH_UNROLLED(X)
+            if (spec_is<__VA_ARGS__>(*spec))                                                                 \
+                return ld_u_fly_f64_##TAG(sim, ep, spec, coins, walls, genomes, fstate, istate, n, stream);
+            LD_FOR_EACH_UNROLLED(X)
 #undef X
+        }
     }
     return launch_fly_step<Real, Faithful, ld::GenericNet<Real, !Faithful>>(sim, ep, spec, coins, walls, genomes, fstate,
                                                                            istate, n, stream);
@@ -85,16 +82,19 @@ int dispatch_mlp(const ld_mlp_spec* spec, const Real* genomes, const Real* input
     return launch_mlp<Real, ld::GenericNet<Real, Fma>>(spec, genomes, inputs, outputs, n, stream);
 }
 
-// Wavefronts per 64-drone genome block for the split kernel (ld_split.hpp): the most that still fits the
-// grid into one round of resident wavefronts -- 1 024 at L <= 4 (a wavefront of those kernels owns its
-// SIMD's registers), 2 048 at L = 8.
-int auto_waves_per_block(int64_t n)
+// Wavefronts per 64-drone genome block for the split kernel (ld_split.hpp), from the measured grid
+// (scripts/ab_grid.py, profiles/r02_split_grid.json): a launch of several timesteps wants about two
+// wavefronts per SIMD chip-wide (2 048), a launch of one timestep about one (1 024: its fixed latency chain
+// -- state load, rigid-body step, barriers -- grows with the wavefronts per block); the 64-wide nets stop at 4
+// (their L = 8 kernel has the registers for a 16-word ring only at two wavefronts per SIMD).
+int auto_waves_per_block(const ld_mlp_spec* spec, int64_t n, int32_t n_steps)
 {
     const int64_t blocks = (n + 63) / 64;
-    if (blocks * 8 <= 2048) return 8;
-    if (blocks * 4 <= 1024) return 4;
-    if (blocks * 2 <= 1024) return 2;
-    return 1;
+    const int64_t target = n_steps > 1 ? 2048 : 1024;
+    const int cap = ld_mlp_words_per_drone(spec) > 512 ? 4 : 8;
+    int waves = 1;
+    while (waves * 2 <= cap && blocks * waves * 2 <= target) waves *= 2;
+    return waves;
 }
 
 // n_steps loop iterations in one launch, float32, unrolled specs only (LD_ERR_SPEC otherwise).
@@ -102,7 +102,7 @@ int dispatch_split_f32(const ld_sim_params* sim, const ld_episode_params* ep, co
                        const double* walls, const float* genomes, float* fstate, int32_t* istate, int64_t n,
                        int32_t n_steps, int32_t waves, hipStream_t stream)
 {
-    if (waves == 0) waves = auto_waves_per_block(n);
+    if (waves == 0) waves = auto_waves_per_block(spec, n, n_steps);
 #define X(TAG, ...)                                                                                          \
     if (spec_is<__VA_ARGS__>(*spec))                                                                         \
         return ld_u_split_f32_##TAG(sim, ep, coins, walls, genomes, fstate, istate, n, n_steps, waves, stream);
@@ -144,8 +144,7 @@ int fly_step_impl(const ld_sim_params* sim, const ld_episode_params* ep, const l
     const int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
     if (rc || n == 0) return rc;                    // an empty population is a no-op
     if constexpr (sizeof(Real) == 4) {
-        static const bool legacy = getenv("LD_STEP_LEGACY") != nullptr;       // A/B switch, read once
-        if (!legacy && has_unrolled(*spec))
+        if (has_unrolled(*spec))
             return dispatch_split_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, 1, 0,
                                       static_cast<hipStream_t>(stream));
     }
@@ -169,13 +168,11 @@ int finalize_impl(const ld_episode_params* ep, const double* coins, const Real* 
     return check_launch("finalize_kernel");
 }
 
-// Loop iterations per launch chosen for a shard: 1 (the contract: one launch advances the population one
-// timestep) unless a launch moves so few bytes that the kernel boundary (~1.5-2 us) would dominate it.
-int auto_steps_per_launch(const ld_mlp_spec* spec, int64_t n)
-{
-    const int64_t bytes = n * (4 * ld_mlp_param_count(spec) + 200);
-    return bytes <= (int64_t)LD_MULTISTEP_MAX_BYTES ? LD_MULTISTEP_STEPS : 1;
-}
+// Loop iterations per launch of a rollout.  Every size gains from keeping the drone state in registers
+// across timesteps and dropping the per-step kernel boundary (65 536 x 32-32: 67.6 -> 62.9 us per step at
+// 16, 62.4 at 64; 8 192: 13.3 -> 9.3; 1 024 x 16-16: 7.7 -> 2.7), with little left beyond 16, which keeps
+// the launch count of a 2 000-step episode at 125 and the stream responsive.
+int auto_steps_per_launch() { return LD_STEPS_PER_LAUNCH; }
 
 int rollout_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec, const double* coins,
                       const double* walls, const float* genomes, float* fstate, int32_t* istate,
@@ -187,7 +184,7 @@ int rollout_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, con
     int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
     if (rc || n == 0) return rc;
     if (!has_unrolled(*spec)) return LD_ERR_SPEC;
-    if (steps_per_launch == 0) steps_per_launch = auto_steps_per_launch(spec, n);
+    if (steps_per_launch == 0) steps_per_launch = auto_steps_per_launch();
     for (int32_t t = 0; t < timesteps; t += steps_per_launch) {
         const int32_t k = timesteps - t < steps_per_launch ? timesteps - t : steps_per_launch;
         rc = dispatch_split_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, k, waves,
@@ -204,8 +201,7 @@ int rollout_impl(const ld_sim_params* sim, const ld_episode_params* ep, const ld
 {
     if (timesteps < 0) return LD_ERR_SIZE;
     if constexpr (sizeof(Real) == 4) {
-        static const bool legacy = getenv("LD_STEP_LEGACY") != nullptr;
-        if (!legacy && spec && check_spec(spec) == LD_OK && has_unrolled(*spec))
+        if (spec && check_spec(spec) == LD_OK && has_unrolled(*spec))
             return rollout_steps_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, records, n, timesteps, 0, 0, stream);
     }
     for (int32_t t = 0; t < timesteps; ++t) {
@@ -400,6 +396,20 @@ int ld_fly_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, cons
     if (!has_unrolled(*spec)) return LD_ERR_SPEC;
     return dispatch_split_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, n_steps, waves_per_block,
                               static_cast<hipStream_t>(stream));
+}
+
+int ld_fly_rollout_geometry_f32(const ld_mlp_spec* spec, int64_t n, int32_t timesteps, int32_t* steps_per_launch,
+                                int32_t* waves_per_block, int32_t* n_launches)
+{
+    const int rc = check_spec(spec);
+    if (rc) return rc;
+    if (n < 0 || timesteps < 0) return LD_ERR_SIZE;
+    if (!steps_per_launch || !waves_per_block || !n_launches) return LD_ERR_NULL;
+    const bool split = has_unrolled(*spec);
+    *steps_per_launch = split ? auto_steps_per_launch() : 1;
+    *waves_per_block = split ? auto_waves_per_block(spec, n, *steps_per_launch) : 1;
+    *n_launches = (timesteps + *steps_per_launch - 1) / *steps_per_launch;
+    return LD_OK;
 }
 
 int ld_fly_rollout_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,

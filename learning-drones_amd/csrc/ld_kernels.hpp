@@ -359,8 +359,6 @@ int launch_mlp(const ld_mlp_spec* spec, const Real* genomes, const Real* inputs,
     X(16, 16) X(32, 32) X(64, 64) X(8_8, 8, 8) X(24_24, 24, 24) X(48_48, 48, 48) X(64_64, 64, 64) X(32_32_32, 32, 32, 32)
 
 #define LD_DECLARE_UNROLLED(TAG, ...)                                                                            \
-    int ld_u_fly_f32_##TAG(const ld_sim_params*, const ld_episode_params*, const ld_mlp_spec*, const double*,    \
-                           const double*, const float*, float*, int32_t*, int64_t, hipStream_t);                 \
     int ld_u_fly_f64_##TAG(const ld_sim_params*, const ld_episode_params*, const ld_mlp_spec*, const double*,    \
                            const double*, const double*, double*, int32_t*, int64_t, hipStream_t);               \
     int ld_u_mlp_f32_##TAG(const ld_mlp_spec*, const float*, const float*, float*, int64_t, hipStream_t);        \

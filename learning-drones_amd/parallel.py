@@ -125,10 +125,11 @@ class ShardedPopulation:
         """rows_global: [n_total, P] on every rank (host array or tensor); each rank keeps its slice."""
         self.local.set_genomes(rows_global[self.begin:self.end])
 
-    def fly(self, timesteps: int, engine: str = "step"):
+    def fly(self, timesteps: int, engine: str = "step", **geometry):
         """Rollout of the local shard, then the generation-end all-gather.  Returns the [n_total, 4]
-        int32 record tensor (global drone order) on every rank."""
-        local = self.local.fly(timesteps, engine=engine)
+        int32 record tensor (global drone order) on every rank.  `geometry`: steps_per_launch /
+        waves_per_block of Population.fly."""
+        local = self.local.fly(timesteps, engine=engine, **geometry)
         return gather_records(local, self.n_total, self.group)
 
     @staticmethod
@@ -152,10 +153,14 @@ class DeviceEvolution:
     Multi-GPU: tournament selection draws parents uniformly over the WHOLE population
     (evolve/util.py:9-14), so children on rank r need genomes that live on other ranks.  Every rank
     runs the same Philox-keyed selection for its own children on the same gathered fitness vector and
-    then fetches exactly the distinct parents it needs with two all-to-alls (exchange="alltoall":
-    requested indices, then genome rows; about one shard's worth of genes in and out per rank, 1/W of
-    an all-gather).  exchange="allgather" is the simple variant: all-gather every shard (cfg3: 446 MB
-    per rank) and breed from the gathered copy."""
+    then fetches exactly the distinct parents it needs (exchange="alltoall": four all_to_all_single
+    calls -- request counts, requested indices, row counts, genome rows -- about one shard's worth of
+    genes in and out per rank, 1/W of an all-gather).  exchange="allgather" is the simple variant:
+    all-gather every shard (cfg3: 446 MB per rank) and breed from the gathered copy; it is what runs on
+    backends without a device all-to-all (gloo).  Collectives per generation: one all_gather_into_tensor
+    of the 16-byte records, one broadcast of the elite genome when the global best improves, and the
+    parent exchange above.  The all-to-all path has run on gloo-backed CPU tensors and in threaded
+    single-GPU rehearsals only; it is unverified on RCCL until a multi-GPU record exists."""
 
     def __init__(self, population: "ShardedPopulation", ga=None, seed: int = 0, engine: str = "auto",
                  exchange: str = "alltoall"):
@@ -209,17 +214,13 @@ class DeviceEvolution:
         if pop.world > 1 and pop.n_total % pop.world:
             raise ValueError("the device generation step needs equal shards (n_total divisible by the world size)")
         if pop.world > 1 and self.exchange == "alltoall" and not self._alltoall_checked:
-            # a backend without all-to-all on device tensors (gloo) raises on every rank alike at the
-            # first call; all ranks then take the all-gather variant together
-            try:
-                DistComm(pop.group).all_to_all([torch.zeros((1,), dtype=torch.int64, device=pop.local.device)
-                                                for _ in range(pop.world)])
-            except RuntimeError as err:
+            # Chosen from the backend's NAME, identically on every rank and before any collective is
+            # issued: probing with a try/except could let one rank fall back while another does not
+            # (collective errors surface asynchronously), after which the ranks would wait in different
+            # collectives.  gloo has no all-to-all on device tensors; nccl (= RCCL on ROCm) does.
+            import torch.distributed as dist
+            if dist.get_backend(pop.group) != "nccl":
                 self.exchange = "allgather"
-                if pop.rank == 0:
-                    import sys
-                    print(f"[learning-drones_amd] all-to-all unavailable on this backend ({err}); using all-gather",
-                          file=sys.stderr)
             self._alltoall_checked = True
         if pop.world > 1 and self.exchange == "alltoall":
             # only the selected parents travel (~1/W of an all-gather)

@@ -276,6 +276,15 @@ class Population:
         self._finalized = True
         return self.records
 
+    def rollout_geometry(self, timesteps: int) -> dict:
+        """What fly(timesteps) (step engine, default geometry) launches: loop iterations per launch,
+        wavefronts per genome block, fused-step launches per episode (ld_fly_rollout_geometry_f32)."""
+        k, w, m = C.c_int32(1), C.c_int32(1), C.c_int32(int(timesteps))
+        if self.precision == "f32":
+            _native.check(_native.lib().ld_fly_rollout_geometry_f32(C.byref(self.spec), self.n, int(timesteps), C.byref(k),
+                                                                    C.byref(w), C.byref(m)), "ld_fly_rollout_geometry_f32")
+        return {"steps_per_launch": k.value, "waves_per_block": w.value, "launches": m.value}
+
     def results(self) -> np.ndarray:
         """Host copy of the result records as a structured array with the extra convenience fields
         of fly()/Drone: reward, flight_time, coins, crashed, distance_to_coin."""
@@ -393,7 +402,13 @@ class Population:
     # ------------------------------------------------------------------ accounting
     @property
     def bytes_per_drone_step(self) -> int:
-        """Algorithmic HBM bytes of one fused drone-step: genes once + 25 state words read and
-        written (4P + 200 for float32)."""
+        """Algorithmic HBM bytes of one fused drone-step in a one-step launch: genes once + 25 state
+        words read and written (4P + 200 for float32)."""
         word = 4 if self.precision == "f32" else 8
         return word * (self.P + 2 * F_COUNT) + 4 * 2 * I_COUNT
+
+    def bytes_per_launch(self, steps_per_launch: int = 1) -> int:
+        """Algorithmic bytes of one fused launch of `steps_per_launch` timesteps: the genes once per
+        timestep, the state read and written once per LAUNCH (it stays in registers in between)."""
+        word = 4 if self.precision == "f32" else 8
+        return self.n * (steps_per_launch * word * self.P + word * 2 * F_COUNT + 4 * 2 * I_COUNT)

@@ -463,7 +463,7 @@ def test_split_waves_and_multistep_are_bit_identical(Population, torch, generic_
         ref.step()
     generic_kernels(False)
     crashed = (ref.istate[2] & 1).bool()
-    assert crashed.any() and not crashed.all() and int(ref.istate[1].max()) >= 1
+    assert crashed.any() and not crashed.all()
     for waves in (0, 1, 2, 4, 8):
         for k in (1, 7, T):
             if k == 1 and waves in (2, 4) and hidden != (32, 32):

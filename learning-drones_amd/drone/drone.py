@@ -10,6 +10,7 @@ import numpy as np
 from ..evolve.brain import NeuralNetwork
 from ..params import EpisodeParams, SimParams, flatten_weights
 from .onboard_computer import ControlUnit
+from .quadcopter import QuadcopterPhysics
 
 delta_t = 0.01                               # drone/drone.py:10
 
@@ -46,7 +47,7 @@ class Drone(ControlUnit):
         # port / visualize / n_servers are accepted for signature compatibility; the TCP data scraper
         # and the viewers are out of scope, so no directory is created either.
         self.precision = precision
-        self.quadcopter = SimParams.reference()          # uniform physics block (physical_model.py:37-73)
+        self.quadcopter = QuadcopterPhysics(precision=precision)   # drone.py:34-47; calculate_accelerations() on the GPU
         self.dh = None
         self._initial = [_column(v, 3) for v in (initial_pos, initial_vel, initial_angle, initial_angle_vel)]
         self.controller = NeuralNetwork(layer_spec={1: 10, 2: 10, 3: 4}, precision=precision)   # drone.py:65
@@ -95,7 +96,7 @@ class Drone(ControlUnit):
     def measure(self, wind_speed):
         """One physics + integration step with crash / instability reward (drone.py:129-165)."""
         pop = self._population()
-        pop.sim = SimParams.reference(wind=np.asarray(wind_speed, float).ravel())
+        pop.sim = self.quadcopter.sim_params(wind_speed)
         pop.episode = EpisodeParams.reference(n_coins=pop.episode.n_coins)
         pop.reset()
         pop.set_state(self._state12()[None], self._acc6()[None], self.thrust.reshape(1, 4))
@@ -124,7 +125,7 @@ class Drone(ControlUnit):
         from ..params import INITIAL_STATE
         s = np.asarray(INITIAL_STATE)                    # parameters.py:49-52, as drone.py:183-186 does
         self._clear([s[0:3].reshape(3, 1), s[3:6].reshape(3, 1), s[6:9].reshape(3, 1), s[9:12].reshape(3, 1)])
-        self.quadcopter = SimParams.reference()
+        self.quadcopter = QuadcopterPhysics(precision=self.precision)
 
     @property
     def genes(self):

@@ -28,6 +28,17 @@ class NeuralNetwork(ControlUnit):
     def spec(self) -> MlpSpec:
         return MlpSpec.from_layer_spec(self.layer_spec, self.layer_spec[0])
 
+    # brain.py:26-39: the activation helpers, for callers that use them directly (the GPU forward pass
+    # applies the same two functions inside ld_mlp_forward_*)
+    def _relu(self, x, thresh=0, alpha=1.0):
+        return 0.0 if x < thresh else alpha * x
+
+    def relu(self, x_vec, thresh=0, alpha=1.0):
+        return np.array([[self._relu(x, thresh=thresh, alpha=alpha) for x in np.squeeze(x_vec)]]).T
+
+    def sigmoid(self, x, beta=0.4):
+        return 1 / (np.exp(-beta * x) + 1)
+
     def feed_forward(self, input_vec):
         x = np.asarray(input_vec, dtype=np.float64)
         if x.ndim != 2 or x.shape[1] != 1:
@@ -35,7 +46,7 @@ class NeuralNetwork(ControlUnit):
         from ..scalar import scalar_population
         pop = scalar_population(self.spec, self.precision)
         pop.set_genomes(flatten_weights(self.weights)[None, :])
-        return pop.feed_forward(x).double().cpu().numpy().reshape(4, 1)
+        return pop.feed_forward(x).double().cpu().numpy().reshape(-1, 1)
 
     def translate_input_to_thrust(self, drone_position, drone_velocity, drone_angle, drone_angle_velocity,
                                   coin_position):

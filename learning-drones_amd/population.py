@@ -343,11 +343,19 @@ class Population:
     # ------------------------------------------------------------------ checkpoint / replay
     def state_dict(self) -> dict:
         """Everything needed to continue this population elsewhere (host numpy arrays)."""
-        return {"n": self.n, "hidden": np.array(self.spec.hidden_widths, np.int32), "precision": self.precision,
-                "genes": self.get_genomes().cpu().numpy(), "fstate": self.fstate.cpu().numpy(),
-                "istate": self.istate.cpu().numpy(), "records": self.records.cpu().numpy(),
-                "coins": self.coins_host, "walls": self.walls_host, "init_state": self.init_state,
-                "finalized": self._finalized}
+        d = {"n": self.n, "hidden": np.array(self.spec.hidden_widths, np.int32), "precision": self.precision,
+             "genes": self.get_genomes().cpu().numpy(), "fstate": self.fstate.cpu().numpy(),
+             "istate": self.istate.cpu().numpy(), "records": self.records.cpu().numpy(),
+             "coins": self.coins_host, "walls": self.walls_host, "init_state": self.init_state,
+             "finalized": self._finalized,
+             # the uniform blocks as the raw bytes of struct ld_sim_params / ld_episode_params (wind, payload,
+             # dt; reward signs, limits, crash planes, coin_respawn), with the ABI version that laid them out
+             "sim": np.frombuffer(bytes(self.sim), np.uint8).copy(),
+             "episode": np.frombuffer(bytes(self.episode), np.uint8).copy(),
+             "abi_version": _native.ABI_VERSION}
+        if self.distance is not None:
+            d["distance"] = self.distance.cpu().numpy()
+        return d
 
     def save(self, path: str) -> None:
         np.savez_compressed(path, **self.state_dict())
@@ -356,12 +364,20 @@ class Population:
     def load(cls, path: str, device: Optional[str] = None) -> "Population":
         torch = _torch()
         z = np.load(path, allow_pickle=False)
+        if "sim" not in z or int(z["abi_version"]) != _native.ABI_VERSION:
+            raise ValueError(f"{path}: checkpoint without the physics / episode blocks of ABI version {_native.ABI_VERSION} "
+                             "(written by an older build); it cannot be resumed faithfully")
+        sim = SimParams.from_buffer_copy(z["sim"].tobytes())
+        episode = EpisodeParams.from_buffer_copy(z["episode"].tobytes())
         pop = cls(int(z["n"]), tuple(int(h) for h in z["hidden"]), precision=str(z["precision"]), device=device,
-                  coins=z["coins"], walls=z["walls"] if len(z["walls"]) else None, init_state=z["init_state"])
+                  sim=sim, episode=episode, coins=z["coins"], walls=z["walls"] if len(z["walls"]) else None,
+                  init_state=z["init_state"], coin_respawn=bool(episode.coin_respawn))
         pop.set_genomes(z["genes"])
         pop.fstate.copy_(torch.from_numpy(z["fstate"]))
         pop.istate.copy_(torch.from_numpy(z["istate"]))
         pop.records.copy_(torch.from_numpy(z["records"]))
+        if pop.distance is not None and "distance" in z:
+            pop.distance.copy_(torch.from_numpy(z["distance"]))
         pop._finalized = bool(z["finalized"])
         return pop
 

@@ -1,0 +1,317 @@
+"""GPU tests added in round 2: the unbounded coin chain at and beyond the table's end, checkpoints of
+non-default physics / episode blocks, the accelerations-only entry point and its drop-in shim, the
+reference's marginal ("noisy") closed-loop episodes on the float32 kernels, BASELINE config 4 at its
+shard size, and ShardedPopulation over several ranks on one GPU at the config-4 and config-5 shard sizes."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from learning_drones_amd.params import EpisodeParams, MlpSpec, SimParams, coin_chain_reference
+
+pytestmark = pytest.mark.gpu
+RTOL_F32 = 1e-4                                  # BASELINE.json north_star: "matching CPU reference trajectories to rtol=1e-4"
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch
+
+
+@pytest.fixture(scope="module")
+def Population(torch):
+    from learning_drones_amd.population import Population
+    return Population
+
+
+def _hover_genes(hidden, n, sigma=1e-4, seed=0):
+    from learning_drones_amd import controllers
+    rng = np.random.default_rng(seed)
+    bases = [controllers.hover_net(hidden, gains=controllers.hover_gains(pole_xy=p)) for p in (1.2, 1.6, 2.0, 2.5)]
+    return np.stack([np.concatenate([w.ravel() for w in controllers.perturbed(bases[i % 4], sigma, rng)])
+                     for i in range(n)]).astype(np.float32).astype(np.float64)
+
+
+# ------------------------------------------------------------------------------------------- coin chain
+@pytest.mark.parametrize("precision,engine", [("f64", "step"), ("f32", "step"), ("f32", "resident")])
+def test_coin_chain_beyond_the_table(Population, oracle, precision, engine):
+    """flight/__init__.py:47-52 respawns a coin forever.  A one-row table with coin_respawn (the default
+    Population) must give what a long finite table of the same chain gives, on every engine and on the
+    oracle, for drones that collect well past the first rows; and a finite table stops at its last row."""
+    hidden, n, T = (16, 16), 96, 2500
+    genes = _hover_genes(hidden, n)
+    spec = MlpSpec.from_hidden(hidden)
+    mode = oracle.FAITHFUL_F64 if precision == "f64" else oracle.CLOSED_F32
+    threads = min(oracle.max_threads(), 16)
+
+    def run(**kw):
+        pop = Population(n, hidden, precision=precision, **kw)
+        pop.set_genomes(genes)
+        pop.fly(T, engine=engine)
+        return pop, pop.results()
+
+    pop_chain, chain = run()                                             # reference episode: 1 row + respawn
+    assert pop_chain.episode.n_coins == 1 and pop_chain.episode.coin_respawn == 1
+    _, table = run(coins=coin_chain_reference(40))                       # finite, long enough for everyone
+    _, two = run(coins=coin_chain_reference(2), coin_respawn=True)       # continuation from a 2-row table
+    _, capped = run(coins=coin_chain_reference(2))                       # finite: ends at 2
+    assert chain["coins"].max() >= 6 and chain["coins"].max() < 40
+    for f in ("reward", "coins", "flight_time", "crashed", "distance_to_coin"):
+        assert np.array_equal(chain[f], table[f]), f
+        assert np.array_equal(chain[f], two[f]), f
+    assert capped["coins"].max() == 2 and (capped["coins"] <= 2).all()
+    # a drone that took both coins of the finite chain keeps the last row as its target (controller input and
+    # distance penalty); on the unbounded chain the same drone flies on to the third coin and beyond
+    took_all = capped["coins"] == 2
+    assert took_all.any() and (chain["coins"][took_all] >= 2).all() and (chain["coins"][took_all] > 2).any()
+    assert (capped["reward"][took_all] != chain["reward"][took_all]).any()
+    assert (capped["distance_to_coin"][took_all] < 3.0).mean() > 0.8     # hovering at the last coin of the table
+    # the oracle restates the same rule
+    ref_chain = oracle.fly(pop_chain.sim, pop_chain.episode, spec, genes, T, n_threads=threads, mode=mode)
+    ep_capped = EpisodeParams.reference(n_coins=2, coin_respawn=False)
+    ref_capped = oracle.fly(pop_chain.sim, ep_capped, spec, genes, T, coins=coin_chain_reference(2), n_threads=threads, mode=mode)
+    if precision == "f64":
+        assert np.array_equal(chain["reward"], ref_chain.reward) and np.array_equal(chain["coins"], ref_chain.coins)
+        assert np.array_equal(capped["reward"], ref_capped.reward) and np.array_equal(capped["coins"], ref_capped.coins)
+    else:                                                                # stable flyers: float32 GPU == float32 oracle
+        assert np.mean(chain["reward"] == ref_chain.reward) >= 0.98 and np.array_equal(chain["coins"], ref_chain.coins)
+        assert np.mean(capped["reward"] == ref_capped.reward) >= 0.98 and np.array_equal(capped["coins"], ref_capped.coins)
+
+
+def test_reference_hover_episodes_on_the_unbounded_chain(Population, g3):
+    """The reference's own coin-collecting episodes (3-8 coins) through the default Population, whose coin
+    table is ONE row continued in the kernel: every integer outcome exact (float64 kernels)."""
+    for ei in range(int(g3["n_episodes"])):
+        if str(g3[f"kind_{ei}"]) != "hover":
+            continue
+        hidden = tuple(int(h) for h in g3[f"hidden_{ei}"])
+        pop = Population(1, hidden, precision="f64")
+        pop.set_genomes(g3[f"weights_{ei}"][None])
+        pop.fly(int(g3[f"timesteps_{ei}"]))
+        r, fin = pop.results()[0], g3[f"final_{ei}"]
+        assert (int(r["reward"]), int(r["coins"]), int(r["flight_time"]), bool(r["crashed"])) == \
+               (int(fin[0]), int(fin[2]), int(fin[3]), bool(fin[4]))
+        assert abs(r["distance_to_coin"] - fin[5]) < 1e-8 and int(r["coins"]) >= 3
+
+
+# ------------------------------------------------------------------------------------------- checkpoints
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_checkpoint_keeps_physics_and_episode_blocks(Population, torch, tmp_path, precision):
+    """A population with wind, payload, punish_time, other crash planes, a finite coin table and walls,
+    saved mid-episode and continued after load(), must end bit for bit like the uninterrupted run
+    (the float64 distance included)."""
+    hidden, n = (16, 16), 130
+    genes = _hover_genes(hidden, n, sigma=0.004, seed=3)
+    sim = SimParams.reference(wind=(0.4, -0.2, 0.1), mass_payload=0.03, x_payload=0.02, y_payload=-0.01, dt=0.008)
+    ep = EpisodeParams.reference(punish_time=True, reward_time=False)
+    ep.z_ceiling, ep.angle_limit = 30.0, 0.6
+    walls = np.array([[6.0, 4.0, 8.0, 7.0, 8.0, 12.0]])
+
+    def make():
+        pop = Population(n, hidden, precision=precision, sim=SimParams.from_buffer_copy(sim), episode=EpisodeParams.from_buffer_copy(ep),
+                         coins=coin_chain_reference(2), walls=walls)
+        pop.set_genomes(genes)
+        return pop
+
+    straight = make()
+    for _ in range(300):
+        straight.step()
+    straight.finalize()
+    first = make()
+    for _ in range(120):
+        first.step()
+    first.save(str(tmp_path / "mid.npz"))
+    resumed = Population.load(str(tmp_path / "mid.npz"))
+    assert bytes(resumed.sim) == bytes(first.sim) and bytes(resumed.episode) == bytes(first.episode)
+    assert resumed.episode.reward_time == -2 and resumed.episode.coin_respawn == 0 and resumed.sim.dt == 0.008
+    for _ in range(180):
+        resumed.step()
+    resumed.finalize()
+    assert torch.equal(resumed.fstate, straight.fstate) and torch.equal(resumed.istate, straight.istate)
+    assert torch.equal(resumed.records, straight.records)
+    if precision == "f64":
+        assert torch.equal(resumed.distance, straight.distance) and float(resumed.distance.max()) > 0
+    # a finalized float64 population keeps its distances through save / load
+    straight.save(str(tmp_path / "end.npz"))
+    again = Population.load(str(tmp_path / "end.npz"))
+    assert np.array_equal(again.results(), straight.results())
+    crashed = straight.results()["crashed"]
+    assert crashed.any() and not crashed.all()
+
+
+# ------------------------------------------------------------------------------------------- accelerations
+def test_accelerations_entry_point_and_shim(torch, g1):
+    """ld_accelerations_* = QuadcopterPhysics.calculate_accelerations (physical_model.py:75-122) alone, against
+    the reference's own vectors; and the drop-in shim drone.quadcopter.calculate_accelerations."""
+    import ctypes as C
+    from learning_drones_amd import _native
+    from learning_drones_amd.drone.drone import Drone
+    n = 1500                                                             # the wind-free vectors of G1
+    state, thrust, acc = g1["state_in"][:n], g1["thrust"][:n], g1["acc_out"][:n]
+    sim = SimParams.reference()
+    tame = np.abs(np.cos(state[:, 7])) > 0.05                            # float32: away from the cos(pitch) = 0 pole
+    for name, dtype, tol, rows in (("f64", torch.float64, 1e-11, np.ones(n, bool)), ("f32", torch.float32, 1e-3, tame)):
+        ang = torch.as_tensor(state[:, 6:9].T.copy()).to("cuda", dtype).contiguous()
+        thr = torch.as_tensor(thrust.T.copy()).to("cuda", dtype).contiguous()
+        lin, rot = torch.empty_like(ang), torch.empty_like(ang)
+        fn = getattr(_native.lib(), f"ld_accelerations_{name}")
+        _native.check(fn(C.byref(sim), C.c_void_p(ang.data_ptr()), C.c_void_p(thr.data_ptr()), C.c_void_p(lin.data_ptr()),
+                         C.c_void_p(rot.data_ptr()), n, None), "ld_accelerations")
+        got = torch.cat([lin, rot]).t().double().cpu().numpy()
+        scale = np.maximum(np.abs(acc), 1.0)
+        assert np.max((np.abs(got - acc) / scale)[rows]) < tol, name
+        assert fn(None, None, None, None, None, 1, None) == -1 and fn(C.byref(sim), None, None, None, None, 0, None) == 0
+    # wind + payload vectors: the reference's calculate_accelerations outputs themselves
+    pp = g1["payload_params"]
+    from learning_drones_amd.drone.quadcopter import QuadcopterPhysics
+    q = QuadcopterPhysics(mass_payload=pp[0], x_payload=pp[1], y_payload=pp[2], I_x=pp[3], I_y=pp[4], I_z=pp[5])
+    for i in (0, 57, len(g1["payload_angle"]) - 1):
+        lin, rot = q.calculate_accelerations(g1["payload_angle"][i].reshape(3, 1), g1["payload_wind"][i].reshape(3, 1),
+                                             g1["payload_thrust"][i].reshape(4, 1), True)
+        ref = np.concatenate([g1["payload_lin_acc"][i], g1["payload_rot_acc"][i]])
+        assert np.max(np.abs(np.concatenate([lin, rot]).ravel() - ref) / np.maximum(np.abs(ref), 1.0)) < 1e-11
+    d = Drone(visualize=False)
+    k = 7
+    lin, rot = d.quadcopter.calculate_accelerations(state[k, 6:9].reshape(3, 1), np.zeros((3, 1)), thrust[k].reshape(4, 1),
+                                                    lin_acc_drone_2_lab=True)
+    assert lin.shape == (3, 1) and rot.shape == (3, 1)
+    assert np.max(np.abs(np.concatenate([lin, rot]).ravel() - acc[k]) / np.maximum(np.abs(acc[k]), 1.0)) < 1e-11
+    assert d.quadcopter.G == pytest.approx(3.924) and d.quadcopter.c_f == 5 and d.quadcopter.m_c == 0.2
+    with pytest.raises(NotImplementedError):
+        d.quadcopter.calculate_accelerations(np.zeros((3, 1)), np.zeros((3, 1)), np.zeros((4, 1)), lin_acc_drone_2_lab=False)
+    nn = d.controller                                                     # evolve/brain.py:26-39 helpers
+    assert np.array_equal(nn.relu(np.array([[-1.0], [2.0], [0.0]])), [[0.0], [2.0], [0.0]]) and nn._relu(-3) == 0.0
+    assert nn.sigmoid(0.0) == 0.5 and abs(nn.sigmoid(2.5) - 1 / (np.exp(-1.0) + 1)) < 1e-15
+
+
+# ------------------------------------------------------------------------------------------- float32 on marginal flights
+def test_noisy_reference_episodes_f32(Population, g3):
+    """The six marginal 32-32 episodes of golden G3 (hover controllers with destabilising gene noise: one
+    survives 2 000 steps, five tumble and crash after 144-460) on the float32 production kernels.  While
+    a flight is still regular the float32 trajectory follows the reference to north_star's rtol = 1e-4 of
+    the distance flown; the comparison stops where the reference flight starts tumbling (|angle| beyond the
+    stability limit: from there a 1-ulp difference is amplified ~10x every 15 steps, tests above), and
+    the crash itself must come within a few steps of the reference's."""
+    seen = 0
+    for ei in range(int(g3["n_episodes"])):
+        if str(g3[f"kind_{ei}"]) != "noisy":
+            continue
+        hidden = tuple(int(h) for h in g3[f"hidden_{ei}"])
+        steps, ref, fin = g3[f"steps_{ei}"], g3[f"state_{ei}"], g3[f"final_{ei}"]
+        pop = Population(1, hidden, precision="f32")
+        pop.set_genomes(g3[f"weights_{ei}"][None])
+        tumbling = np.nonzero((np.abs(ref[:, 6]) > np.pi / 4) | (np.abs(ref[:, 7]) > np.pi / 4))[0]
+        horizon = int(steps[tumbling[0]]) if len(tumbling) else int(steps[-1])
+        done, worst, checked = 0, 0.0, 0
+        for s, want in zip(steps, ref):
+            if s + 1 > horizon:
+                break
+            pop.steps(int(s) + 1 - done, 0)                              # state after loop iteration s
+            done = int(s) + 1
+            got = pop.state_numpy()[0, :12]
+            flown = np.linalg.norm(want[:3] - [0, 0, 10]) + 1.0
+            worst = max(worst, np.max(np.abs(got[:3] - want[:3])) / flown)
+            checked += 1
+        assert checked >= 5 and worst < RTOL_F32, (ei, horizon, worst)
+        pop.steps(int(g3[f"timesteps_{ei}"]) - done, 0)
+        pop.finalize()
+        r = pop.results()[0]
+        assert bool(r["crashed"]) == bool(fin[4]), ei
+        if fin[4]:
+            assert abs(int(r["flight_time"]) - int(fin[3])) <= max(3, int(0.1 * fin[3])), (ei, int(r["flight_time"]), int(fin[3]))
+        else:
+            assert int(r["flight_time"]) == int(fin[3]) and int(r["coins"]) == int(fin[2])
+        seen += 1
+    assert seen == 6
+
+
+# ------------------------------------------------------------------------------------------- config 4 and sharding
+def _replicated(hidden, m, n, seed):
+    """n genomes drawn from an m-drone mixed population under a fixed permutation: (small genomes [m, P],
+    source index of every big-population slot [n])."""
+    from test_gpu_parity import _mixed_genomes
+    spec, genes_m, _ = _mixed_genomes(hidden, m, seed=seed)
+    src = (np.arange(n) % m)[np.random.default_rng(seed).permutation(n)]
+    return genes_m, src
+
+
+def test_full_size_config4_shard(Population, torch):
+    """One GPU's share of BASELINE config 4: 32 768 drones x 4 000 steps, 15-32-32-4, 3-coin chain (the
+    launch geometry this shard gets: 4 wavefronts per block, 16 timesteps per launch).  Size-independent
+    properties: genomes replicated from a 256-drone population under a random permutation give the
+    permuted small-population results bit for bit; a re-run is bit-identical; one launch per timestep
+    and the resident engine give the same records."""
+    hidden, n, T, m = (32, 32), 32768, 4000, 256
+    genes_m, src = _replicated(hidden, m, n, seed=4)
+    coins = coin_chain_reference(3)
+    small = Population(m, hidden, coins=coins)
+    small.set_genomes(genes_m)
+    small.fly(T)
+    want = small.results()
+    pop = Population(n, hidden, coins=coins)
+    pop.set_genomes(torch.as_tensor(genes_m, dtype=torch.float32, device="cuda")[torch.as_tensor(src, device="cuda")])
+    geo = pop.rollout_geometry(T)
+    assert geo == {"steps_per_launch": 16, "waves_per_block": 4, "launches": 250}
+    pop.fly(T)
+    got = pop.results()
+    for f in ("reward", "flight_time", "coins", "crashed", "distance_to_coin"):
+        assert np.array_equal(got[f], want[f][src]), f
+    rec = pop.records.clone()
+    for kw in (dict(steps_per_launch=1), dict(engine="resident"), {}):
+        pop.reset()
+        pop.fly(T, **kw)
+        assert torch.equal(pop.records, rec), kw
+    assert want["coins"].max() == 3 and want["crashed"].any() and not want["crashed"].all()
+
+
+def _shard_worker(rank, world, port, cfg, out_dir):
+    """One rank of a ShardedPopulation on the shared GPU (gloo carries the collectives)."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    sys.path.insert(0, str(REPO)); sys.path.insert(0, str(REPO / "tests"))
+    import torch
+    import torch.distributed as dist
+    from learning_drones_amd.parallel import ShardedPopulation
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        hidden, n_total, T, m, seed, n_coins, walls = cfg
+        genes_m, src = _replicated(hidden, m, n_total, seed)
+        pop = ShardedPopulation(n_total, hidden, process_group=dist.group.WORLD, device="cuda:0",
+                                coins=coin_chain_reference(n_coins), walls=walls)
+        g = torch.as_tensor(genes_m, dtype=torch.float32, device="cuda")
+        pop.local.set_genomes(g[torch.as_tensor(src[pop.begin:pop.end], device="cuda")])
+        records = pop.fly(T)                                              # rollout + all-gather: global order on every rank
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, f"records_{rank}.npy"), records.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,cfg,world", [
+    ("config 4", ((32, 32), 4 * 32768, 4000, 256, 14, 3, None), 4),
+    ("config 5", ((64, 64, 64), 2 * 131072, 400, 192, 15, 5,
+                  np.array([[12.0, 3.0, 8.0, 13.0, 12.0, 12.0], [-20.0, -20.0, 30.0, 20.0, 20.0, 31.0]])), 2),
+])
+def test_sharded_population_equals_unsharded(Population, torch, tmp_path, name, cfg, world):
+    """ShardedPopulation with `world` ranks (one process each, sharing this GPU; gloo carries the
+    all-gather) at the shard sizes of BASELINE configs 4 and 5: every rank's gathered records equal the
+    records of the same population flown unsharded, in global drone order."""
+    import torch.multiprocessing as mp
+    hidden, n_total, T, m, seed, n_coins, walls = cfg
+    port = 29600 + (os.getpid() + len(name)) % 300
+    mp.spawn(_shard_worker, args=(world, port, cfg, str(tmp_path)), nprocs=world, join=True)
+    genes_m, src = _replicated(hidden, m, n_total, seed)
+    whole = Population(n_total, hidden, coins=coin_chain_reference(n_coins), walls=walls)
+    whole.set_genomes(torch.as_tensor(genes_m, dtype=torch.float32, device="cuda")[torch.as_tensor(src, device="cuda")])
+    whole.fly(T)
+    want = whole.records.cpu().numpy()
+    for r in range(world):
+        got = np.load(tmp_path / f"records_{r}.npy")
+        assert got.shape == want.shape and np.array_equal(got, want), (name, r)
+    res = whole.results()
+    assert res["crashed"].any() and not res["crashed"].all() and res["coins"].max() >= 1

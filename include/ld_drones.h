@@ -296,6 +296,30 @@ int ld_fly_rollout_resident_f32(const ld_sim_params *sim, const ld_episode_param
                                 int32_t *istate, ld_fitness_record *records, int64_t n, int32_t timesteps,
                                 void *stream);
 
+/* `n_steps` loop iterations of the genome-resident kernel WITHOUT the finalize launch (the episode can be
+ * continued, e.g. after compacting the survivors; finish with ld_fly_finalize_f32). */
+int ld_fly_steps_resident_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
+                              const double *coins, const double *walls, const float *genomes, float *fstate,
+                              int32_t *istate, int64_t n, int32_t n_steps, void *stream);
+
+/* Compaction of a population.  A wavefront of the rollout kernels runs until its LAST drone has crashed;
+ * in a GA generation most children crash within a few hundred steps, so after a while most lanes of most
+ * wavefronts are frozen.  ld_population_gather_* copies drone idx[j] (device int32[n_dst]) of a source
+ * population (genome words + fstate + istate, n_src drones) into drone j of a destination population of
+ * n_dst drones, which then flies on densely packed; ld_population_scatter_state_* writes the compact
+ * population's state back to drones idx[j] of the home population (genomes never change during an
+ * episode).  Source and destination arrays must not alias. */
+int ld_population_gather_f32(const ld_mlp_spec *spec, const int32_t *idx, int64_t n_dst, const float *src_genomes,
+                             const float *src_fstate, const int32_t *src_istate, int64_t n_src, float *dst_genomes,
+                             float *dst_fstate, int32_t *dst_istate, void *stream);
+int ld_population_gather_f64(const ld_mlp_spec *spec, const int32_t *idx, int64_t n_dst, const double *src_genomes,
+                             const double *src_fstate, const int32_t *src_istate, int64_t n_src, double *dst_genomes,
+                             double *dst_fstate, int32_t *dst_istate, void *stream);
+int ld_population_scatter_state_f32(const int32_t *idx, int64_t n_src, const float *src_fstate, const int32_t *src_istate,
+                                    float *dst_fstate, int32_t *dst_istate, int64_t n_dst, void *stream);
+int ld_population_scatter_state_f64(const int32_t *idx, int64_t n_src, const double *src_fstate, const int32_t *src_istate,
+                                    double *dst_fstate, int32_t *dst_istate, int64_t n_dst, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Generation step on the device: the GA operators of evolve/util.py:5-78 and
  * Drone.mutate (drone/drone.py:167-172) applied to the device genome layout.  Random numbers come
@@ -329,13 +353,18 @@ int ld_ga_select(const ld_ga_params *ga, const ld_mlp_spec *spec, const int32_t 
  * lives in segment g / n_per_segment, slot g % n_per_segment; each segment is a whole genome array of
  * ld_genome_words(spec, n_per_segment) words.  If elite != NULL (device, W words of
  * one genome) global child 0 becomes an unmutated copy of it (evolve/evolution.py:105-107).
- * dst is the children's genome array (n_children drones, same blocked layout); it must not alias src. */
+ * dst is the children's genome array (n_children drones, same blocked layout); it must not alias src.
+ * order (device, int32[n_children], or NULL = identity) places child order[s] of this shard into genome
+ * slot s.  A child's parents, cut points and random draws are keyed by the CHILD index, so every
+ * placement produces the same set of children; the GA driver uses it to put children of long-lived
+ * parents into the same wavefronts (a wavefront of the rollout kernels runs until its last drone has
+ * crashed), keeping the elite in slot 0.  order must be a permutation of 0..n_children-1. */
 int ld_ga_breed_f32(const ld_ga_params *ga, const ld_mlp_spec *spec, const float *src, int64_t n_per_segment,
                     int32_t n_segments, const int32_t *parents, const int32_t *cuts, const float *elite,
-                    int64_t child_begin, int64_t n_children, float *dst, void *stream);
+                    int64_t child_begin, int64_t n_children, const int32_t *order, float *dst, void *stream);
 int ld_ga_breed_f64(const ld_ga_params *ga, const ld_mlp_spec *spec, const double *src, int64_t n_per_segment,
                     int32_t n_segments, const int32_t *parents, const int32_t *cuts, const double *elite,
-                    int64_t child_begin, int64_t n_children, double *dst, void *stream);
+                    int64_t child_begin, int64_t n_children, const int32_t *order, double *dst, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * BASELINE config 1 as a batched device policy: the PID-controlled episode of

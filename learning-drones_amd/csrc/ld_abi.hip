@@ -280,7 +280,7 @@ int layout_impl(Real* rows, int64_t row_stride, Real* genomes, int64_t n, int64_
 template <typename Real>
 int breed_impl(const ld_ga_params* ga, const ld_mlp_spec* spec, const Real* src, int64_t n_per_segment, int32_t n_segments,
                const int32_t* parents, const int32_t* cuts, const Real* elite, int64_t child_begin, int64_t n_children,
-               Real* dst, void* stream)
+               const int32_t* order, Real* dst, void* stream)
 {
     if (!ga) return LD_ERR_NULL;
     const int rc = check_spec(spec);
@@ -296,8 +296,39 @@ int breed_impl(const ld_ga_params* ga, const ld_mlp_spec* spec, const Real* src,
     hipLaunchKernelGGL((ld::ga_breed_kernel<Real>), dim3(blocks_for(W * n_children, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), *ga, lt, reinterpret_cast<const ld::GeneWord<Real>*>(src),
                        n_per_segment, parents, cuts, reinterpret_cast<const ld::GeneWord<Real>*>(elite), child_begin,
-                       n_children, reinterpret_cast<ld::GeneWord<Real>*>(dst));
+                       n_children, order, reinterpret_cast<ld::GeneWord<Real>*>(dst));
     return check_launch("ga_breed_kernel");
+}
+
+template <typename Real>
+int gather_impl(const ld_mlp_spec* spec, const int32_t* idx, int64_t n_dst, const Real* src_genomes, const Real* src_fstate,
+                const int32_t* src_istate, int64_t n_src, Real* dst_genomes, Real* dst_fstate, int32_t* dst_istate, void* stream)
+{
+    const int64_t W = ld_mlp_words_per_drone(spec);
+    if (W < 0) return (int)W;
+    if (n_dst < 0 || n_src < 0) return LD_ERR_SIZE;
+    if (n_dst == 0) return LD_OK;
+    if (n_src == 0) return LD_ERR_SIZE;
+    if (!idx || !src_genomes || !src_fstate || !src_istate || !dst_genomes || !dst_fstate || !dst_istate) return LD_ERR_NULL;
+    if (!aligned16(src_genomes) || !aligned16(dst_genomes)) return LD_ERR_ALIGN;
+    if (src_genomes == dst_genomes || src_fstate == dst_fstate || src_istate == dst_istate) return LD_ERR_SIZE;
+    hipLaunchKernelGGL((ld::population_gather_kernel<Real>), dim3(blocks_for((W + LD_F_COUNT + LD_I_COUNT) * n_dst, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), idx, n_dst, reinterpret_cast<const ld::GeneWord<Real>*>(src_genomes),
+                       src_fstate, src_istate, n_src, reinterpret_cast<ld::GeneWord<Real>*>(dst_genomes), dst_fstate, dst_istate, W);
+    return check_launch("population_gather_kernel");
+}
+
+template <typename Real>
+int scatter_impl(const int32_t* idx, int64_t n_src, const Real* src_fstate, const int32_t* src_istate, Real* dst_fstate,
+                 int32_t* dst_istate, int64_t n_dst, void* stream)
+{
+    if (n_dst < 0 || n_src < 0) return LD_ERR_SIZE;
+    if (n_src == 0) return LD_OK;
+    if (n_dst == 0) return LD_ERR_SIZE;
+    if (!idx || !src_fstate || !src_istate || !dst_fstate || !dst_istate) return LD_ERR_NULL;
+    hipLaunchKernelGGL((ld::population_scatter_state_kernel<Real>), dim3(blocks_for((int64_t)(LD_F_COUNT + LD_I_COUNT) * n_src, 256)),
+                       dim3(256), 0, static_cast<hipStream_t>(stream), idx, n_src, src_fstate, src_istate, dst_fstate, dst_istate, n_dst);
+    return check_launch("population_scatter_state_kernel");
 }
 
 template <typename Real, bool Faithful>
@@ -318,6 +349,32 @@ int pid_impl(const ld_sim_params* sim, const Real* gains, const double* coins, i
 }  // namespace
 
 extern "C" {
+
+int ld_fly_steps_resident_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,
+                              const double* coins, const double* walls, const float* genomes, float* fstate,
+                              int32_t* istate, int64_t n, int32_t n_steps, void* stream)
+{
+    if (n_steps < 0) return LD_ERR_SIZE;
+    const int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
+    if (rc || n == 0 || n_steps == 0) return rc;
+    return ld_resident_dispatch(sim, ep, spec, coins, walls, genomes, fstate, istate, n, n_steps,
+                                static_cast<hipStream_t>(stream));
+}
+
+int ld_population_gather_f32(const ld_mlp_spec* spec, const int32_t* idx, int64_t n_dst, const float* src_genomes,
+                             const float* src_fstate, const int32_t* src_istate, int64_t n_src, float* dst_genomes,
+                             float* dst_fstate, int32_t* dst_istate, void* stream)
+{ return gather_impl<float>(spec, idx, n_dst, src_genomes, src_fstate, src_istate, n_src, dst_genomes, dst_fstate, dst_istate, stream); }
+int ld_population_gather_f64(const ld_mlp_spec* spec, const int32_t* idx, int64_t n_dst, const double* src_genomes,
+                             const double* src_fstate, const int32_t* src_istate, int64_t n_src, double* dst_genomes,
+                             double* dst_fstate, int32_t* dst_istate, void* stream)
+{ return gather_impl<double>(spec, idx, n_dst, src_genomes, src_fstate, src_istate, n_src, dst_genomes, dst_fstate, dst_istate, stream); }
+int ld_population_scatter_state_f32(const int32_t* idx, int64_t n_src, const float* src_fstate, const int32_t* src_istate,
+                                    float* dst_fstate, int32_t* dst_istate, int64_t n_dst, void* stream)
+{ return scatter_impl<float>(idx, n_src, src_fstate, src_istate, dst_fstate, dst_istate, n_dst, stream); }
+int ld_population_scatter_state_f64(const int32_t* idx, int64_t n_src, const double* src_fstate, const int32_t* src_istate,
+                                    double* dst_fstate, int32_t* dst_istate, int64_t n_dst, void* stream)
+{ return scatter_impl<double>(idx, n_src, src_fstate, src_istate, dst_fstate, dst_istate, n_dst, stream); }
 
 int ld_fly_rollout_resident_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,
                                 const double* coins, const double* walls, const float* genomes, float* fstate,
@@ -366,12 +423,12 @@ int ld_ga_select(const ld_ga_params* ga, const ld_mlp_spec* spec, const int32_t*
 
 int ld_ga_breed_f32(const ld_ga_params* ga, const ld_mlp_spec* spec, const float* src, int64_t n_per_segment,
                     int32_t n_segments, const int32_t* parents, const int32_t* cuts, const float* elite,
-                    int64_t child_begin, int64_t n_children, float* dst, void* stream)
-{ return breed_impl<float>(ga, spec, src, n_per_segment, n_segments, parents, cuts, elite, child_begin, n_children, dst, stream); }
+                    int64_t child_begin, int64_t n_children, const int32_t* order, float* dst, void* stream)
+{ return breed_impl<float>(ga, spec, src, n_per_segment, n_segments, parents, cuts, elite, child_begin, n_children, order, dst, stream); }
 int ld_ga_breed_f64(const ld_ga_params* ga, const ld_mlp_spec* spec, const double* src, int64_t n_per_segment,
                     int32_t n_segments, const int32_t* parents, const int32_t* cuts, const double* elite,
-                    int64_t child_begin, int64_t n_children, double* dst, void* stream)
-{ return breed_impl<double>(ga, spec, src, n_per_segment, n_segments, parents, cuts, elite, child_begin, n_children, dst, stream); }
+                    int64_t child_begin, int64_t n_children, const int32_t* order, double* dst, void* stream)
+{ return breed_impl<double>(ga, spec, src, n_per_segment, n_segments, parents, cuts, elite, child_begin, n_children, order, dst, stream); }
 
 int ld_version(void) { return LD_ABI_VERSION; }
 

@@ -87,16 +87,19 @@ __global__ void __launch_bounds__(256)
 ga_breed_kernel(const ld_ga_params ga, const LayerTable lt, const GeneWord<Real>* __restrict__ src,
                 const int64_t n_per_segment, const int32_t* __restrict__ parents, const int32_t* __restrict__ cuts,
                 const GeneWord<Real>* __restrict__ elite, const int64_t child_begin, const int64_t n_children,
-                GeneWord<Real>* __restrict__ dst)
+                const int32_t* __restrict__ order, GeneWord<Real>* __restrict__ dst)
 {
     const int P = lt.offset[lt.n_layers];
     const int64_t W = (P + 3) / 4;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= W * n_children) return;
-    const int64_t w = t / n_children, c = t % n_children;
+    const int64_t w = t / n_children, slot = t % n_children;
+    // `order` places child order[slot] of this shard (its parents, cuts and random draws follow the CHILD,
+    // not the slot) into genome slot `slot`: any placement yields the same set of children
+    const int64_t c = order ? order[slot] : slot;
     const int64_t gchild = child_begin + c;
     if (elite != nullptr && gchild == 0) {                                // evolution.py:105-107
-        dst[word_index(c, w, W)] = elite[w];
+        dst[word_index(slot, w, W)] = elite[w];
         return;
     }
     const int64_t blocks_per_segment = (n_per_segment + kGenomeBlock - 1) / kGenomeBlock;
@@ -143,7 +146,7 @@ ga_breed_kernel(const ld_ga_params ga, const LayerTable lt, const GeneWord<Real>
             v.g[j] = v.g[j] + (Real)((float)ga.mutation_sigma * nrm);
         }
     }
-    dst[word_index(c, w, W)] = v;
+    dst[word_index(slot, w, W)] = v;
 }
 
 }  // namespace ld

@@ -163,19 +163,22 @@ class DeviceEvolution:
     single-GPU rehearsals only; it is unverified on RCCL until a multi-GPU record exists."""
 
     def __init__(self, population: "ShardedPopulation", ga=None, seed: int = 0, engine: str = "auto",
-                 exchange: str = "alltoall"):
+                 exchange: str = "alltoall", pack_by_lifetime: bool = True, compact: bool = True):
         from .params import GaParams
         if exchange not in ("alltoall", "allgather"):
             raise ValueError("exchange must be 'alltoall' or 'allgather'")
         self.pop = population
         self.engine = engine
         self.exchange = exchange
+        self.pack_by_lifetime = pack_by_lifetime       # Population.breed(lifetimes=...): same children, lifetime-sorted slots
+        self.compact = compact                         # Population.fly(compact=True): survivors re-packed between segments
         self._alltoall_checked = False
         self.ga = ga if ga is not None else GaParams.reference(seed=seed)
         self.generation = 0
         self.global_best_score = None
         self.elite = None                      # W x 4 genome words of the best drone so far
         self.history = []
+        self.slot_of = None                    # canonical drone index -> global genome slot (None = identity)
 
     def _gather_genomes(self):
         """All-gather variant of the parent exchange: every rank receives every shard."""
@@ -193,19 +196,26 @@ class DeviceEvolution:
         """One generation.  Returns (best_score, global_best_score, records)."""
         import torch
         pop = self.pop
-        records = pop.fly(timesteps, engine=self.engine)              # rollout + all-gather of records
-        fitness = records[:, 0].contiguous()
+        records = pop.fly(timesteps, engine=self.engine, compact=self.compact)   # rollout + all-gather of records (slot order)
+        # The GA itself works on CANONICAL drone indices: child c of a generation is drone c of the next
+        # one wherever its genome was placed (slot_of), so a run is the same run with or without the
+        # lifetime-sorted placement below.
+        slot_of = self.slot_of
+        canon = records if slot_of is None else records[slot_of]
+        fitness = canon[:, 0].contiguous()
+        lifetimes = records[:, 1].contiguous() if self.pack_by_lifetime else None      # indexed by slot, as breed() reads it
         best_score = int(fitness.max().item())
         # FIRST maximum, as np.argmax (evolution.py:77); torch.argmax does not promise which of several
         # equal maxima it returns, and every rank must name the same owner for the broadcast below
         best_index = int((fitness == best_score).nonzero()[0].item())
+        best_slot = best_index if slot_of is None else int(slot_of[best_index].item())
         if self.global_best_score is None or best_score > self.global_best_score:   # evolution.py:80-83
             self.global_best_score = best_score
             elite = torch.empty((pop.local.W, 4), dtype=pop.local.dtype, device=pop.local.device)
-            owner = next(r for r in range(pop.world) if shard_bounds(pop.n_total, pop.world, r)[0] <= best_index
+            owner = next(r for r in range(pop.world) if shard_bounds(pop.n_total, pop.world, r)[0] <= best_slot
                          < shard_bounds(pop.n_total, pop.world, r)[1])
             if owner == pop.rank:
-                elite.copy_(pop.local.genome_of(best_index - pop.begin))
+                elite.copy_(pop.local.genome_of(best_slot - pop.begin))
             if pop.world > 1:
                 import torch.distributed as dist
                 dist.broadcast(elite, src=dist.get_global_rank(pop.group, owner), group=pop.group)
@@ -224,13 +234,26 @@ class DeviceEvolution:
             self._alltoall_checked = True
         if pop.world > 1 and self.exchange == "alltoall":
             # only the selected parents travel (~1/W of an all-gather)
-            pop.local.breed(fitness, self.ga, elite=self.elite, child_begin=pop.begin,
+            pop.local.breed(fitness, self.ga, elite=self.elite, child_begin=pop.begin, lifetimes=lifetimes, slot_of=slot_of,
                             fetch_parents=lambda parents: exchange_parent_genomes(pop.local.genomes, pop.local.n, parents,
                                                                                   DistComm(pop.group)))
         else:
             src, n_per_segment, n_segments = self._gather_genomes()
             pop.local.breed(fitness, self.ga, elite=self.elite, child_begin=pop.begin, src=src,
-                            n_per_segment=n_per_segment, n_segments=n_segments)
+                            n_per_segment=n_per_segment, n_segments=n_segments, lifetimes=lifetimes, slot_of=slot_of)
+        # where each child went: local placement -> global canonical-index -> slot map for the next generation
+        order = pop.local.last_order
+        if order is None:
+            self.slot_of = None
+        else:
+            local_slot_of = torch.empty_like(order, dtype=torch.int64)
+            local_slot_of[order.long()] = torch.arange(order.numel(), device=order.device) + pop.begin
+            if pop.world > 1:
+                import torch.distributed as dist
+                full = torch.empty((pop.n_total,), dtype=torch.int64, device=order.device)
+                dist.all_gather_into_tensor(full, local_slot_of, group=pop.group)      # 8 bytes per drone
+                local_slot_of = full
+            self.slot_of = local_slot_of
         pop.local.reset()                                             # Drone.reset for every child
         self.generation += 1
         self.history.append((best_score, self.global_best_score))
@@ -248,7 +271,8 @@ class DeviceEvolution:
                              global_best_score=-2**62 if self.global_best_score is None else self.global_best_score,
                              elite=_np.zeros((0, 4)) if self.elite is None else self.elite.cpu().numpy(),
                              history=_np.array(self.history, dtype=_np.int64).reshape(-1, 2),
-                             genes=pop.get_genomes().cpu().numpy(), rank=self.pop.rank, world=self.pop.world)
+                             genes=pop.get_genomes().cpu().numpy(), rank=self.pop.rank, world=self.pop.world,
+                             slot_of=_np.zeros((0,), _np.int64) if self.slot_of is None else self.slot_of.cpu().numpy())
 
     def load(self, path: str) -> None:
         import numpy as _np
@@ -265,5 +289,6 @@ class DeviceEvolution:
         self.global_best_score = None if gb == -2**62 else gb
         self.elite = None if len(z["elite"]) == 0 else torch.as_tensor(z["elite"]).to(self.pop.local.device, self.pop.local.dtype)
         self.history = [tuple(int(v) for v in row) for row in z["history"]]
+        self.slot_of = None if len(z["slot_of"]) == 0 else torch.as_tensor(z["slot_of"]).to(self.pop.local.device)
         self.pop.local.set_genomes(z["genes"])
         self.pop.local.reset()

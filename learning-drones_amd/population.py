@@ -233,8 +233,67 @@ class Population:
     RESIDENT_SPECS = ((8, 10), (10, 10), (16, 16), (32, 32), (64, 64, 64), (16,), (32,), (64,), (8, 8), (24, 24),
                       (48, 48), (64, 64), (32, 32, 32))
 
+    # ------------------------------------------------------------------ compaction (GA generations)
+    COMPACT_FIRST_SEGMENT = 64        # timesteps before the first look at who is still flying
+    COMPACT_MAX_SEGMENT = 512
+    COMPACT_KEEP_ABOVE = 0.75         # re-pack when fewer than this share of the working set is alive
+
+    def _fly_resident_compacting(self, timesteps: int):
+        """fly() on the genome-resident kernel with the survivors re-packed between segments.
+
+        A wavefront of the rollout kernels runs until its LAST drone has crashed.  In a GA generation most
+        mutated children crash within a few hundred steps while a few fly the whole episode, and a child's
+        lifetime is not predictable from its parents' (measured: sorting children by parent lifetime cuts the
+        masked work by 8 %), so after a while nearly every wavefront carries one long flyer and seven frozen
+        lanes.  Here the episode runs in segments (64, 128, 256, 512, 512 ... timesteps); after a segment the
+        drones still flying are gathered -- genome words and state, ld_population_gather_* -- into a dense
+        working population that flies the next segment, and their state goes back to their home slots
+        (ld_population_scatter_state_*).  Every drone still executes exactly its own timesteps with its own
+        genome, so records and final states are bit-identical to the uncompacted rollout (tested)."""
+        torch = _torch()
+        lib = _native.lib()
+        T = int(timesteps)
+        gather, scatter = self._fn("ld_population_gather"), self._fn("ld_population_scatter_state")
+        w_genomes, w_fstate, w_istate, w_n, idx = self.genomes, self.fstate, self.istate, self.n, None
+        t, seg = 0, self.COMPACT_FIRST_SEGMENT
+        while t < T and w_n > 0:
+            k = min(seg, T - t)
+            _native.check(lib.ld_fly_steps_resident_f32(C.byref(self.sim), C.byref(self.episode), C.byref(self.spec),
+                                                        self._ptr(self.coins_dev), self._ptr(self.walls_dev), self._ptr(w_genomes),
+                                                        self._ptr(w_fstate), self._ptr(w_istate), w_n, k, self._stream()),
+                          "ld_fly_steps_resident_f32")
+            t += k
+            seg = min(2 * seg, self.COMPACT_MAX_SEGMENT)
+            if t >= T:
+                break
+            alive = (w_istate[I_STATUS] & 1) == 0
+            n_alive = int(alive.sum().item())                                # the one host round trip per segment
+            if n_alive > self.COMPACT_KEEP_ABOVE * w_n:
+                continue
+            if idx is not None:                                              # everything the working set did goes home first
+                _native.check(scatter(self._ptr(idx), w_n, self._ptr(w_fstate), self._ptr(w_istate), self._ptr(self.fstate),
+                                      self._ptr(self.istate), self.n, self._stream()), "ld_population_scatter_state")
+            if n_alive == 0:
+                w_n, idx = 0, None
+                break
+            keep = alive.nonzero().flatten().to(torch.int32)
+            blocks = (n_alive + GENOME_BLOCK - 1) // GENOME_BLOCK
+            n_genomes = torch.empty((blocks, self.W, GENOME_BLOCK, 4), dtype=self.dtype, device=self.device)
+            n_fstate = torch.empty((F_COUNT, n_alive), dtype=self.dtype, device=self.device)
+            n_istate = torch.empty((I_COUNT, n_alive), dtype=torch.int32, device=self.device)
+            _native.check(gather(C.byref(self.spec), self._ptr(keep), n_alive, self._ptr(w_genomes), self._ptr(w_fstate),
+                                 self._ptr(w_istate), w_n, self._ptr(n_genomes), self._ptr(n_fstate), self._ptr(n_istate),
+                                 self._stream()), "ld_population_gather")
+            idx = keep if idx is None else idx[keep.long()].contiguous()
+            w_genomes, w_fstate, w_istate, w_n = n_genomes, n_fstate, n_istate, n_alive
+        if idx is not None and w_n > 0:
+            _native.check(scatter(self._ptr(idx), w_n, self._ptr(w_fstate), self._ptr(w_istate), self._ptr(self.fstate),
+                                  self._ptr(self.istate), self.n, self._stream()), "ld_population_scatter_state")
+        self.finalize()
+        return self.records
+
     def fly(self, timesteps: int = 2500, engine: str = "step", steps_per_launch: Optional[int] = None,
-            waves_per_block: int = 0):
+            waves_per_block: int = 0, compact: bool = False):
         """fly(drone, timesteps) for every drone, enqueued from C on the current stream.  Returns the
         device tensor of result records ([n, 4] int32 view of ld_fitness_record); see results().
 
@@ -245,7 +304,10 @@ class Population:
         to amortise a kernel boundary take several timesteps per launch.
         engine="resident" (float32, specs RESIDENT_SPECS): one launch for the whole episode with the
         genome held in registers (ld_fly_rollout_resident_f32); bit-identical results, 3-6x faster.
-        engine="auto": resident where available, else step."""
+        engine="auto": resident where available, else step.
+        compact=True (resident engine): re-pack the drones still flying between segments of the episode
+        (_fly_resident_compacting) -- for populations in which most drones crash early (GA generations);
+        bit-identical results."""
         if self._finalized:
             raise RuntimeError("episode already finalized; reset() first")
         args = [C.byref(self.sim), C.byref(self.episode), C.byref(self.spec), self._ptr(self.coins_dev),
@@ -256,6 +318,8 @@ class Population:
         if engine == "resident":
             if self.precision != "f32" or self.spec.hidden_widths not in self.RESIDENT_SPECS:
                 raise ValueError("the resident engine is float32 and covers the specs " + str(self.RESIDENT_SPECS))
+            if compact and self.n > 0:
+                return self._fly_resident_compacting(timesteps)
             args += [self.n, int(timesteps), self._stream()]
             _native.check(_native.lib().ld_fly_rollout_resident_f32(*args), "ld_fly_rollout_resident_f32")
             self._finalized = True
@@ -303,7 +367,8 @@ class Population:
         return self.genomes[slot // GENOME_BLOCK, :, slot % GENOME_BLOCK, :].contiguous()
 
     def breed(self, fitness_all, ga: GaParams, *, elite=None, child_begin: int = 0, src=None,
-              n_per_segment: Optional[int] = None, n_segments: int = 1, fetch_parents=None) -> None:
+              n_per_segment: Optional[int] = None, n_segments: int = 1, fetch_parents=None, lifetimes=None,
+              slot_of=None) -> None:
         """Replace this population's genomes by the next generation (evolve/util.py:5-78 +
         drone/drone.py:167-172 + the elitism of evolve/evolution.py:105-107), on the device.
 
@@ -312,7 +377,23 @@ class Population:
         are read from — n_segments back-to-back arrays of n_per_segment drones (default: this
         population's own genomes, one segment); elite: W x 4 genome words copied unmutated into
         global child 0, or None; fetch_parents: optional callable(parents_global) -> (src genome array,
-        parents re-indexed into it) used by the multi-GPU all-to-all exchange (parallel.py)."""
+        parents re-indexed into it) used by the multi-GPU all-to-all exchange (parallel.py).
+
+        lifetimes: optional int32 device tensor, flight_time of ALL n_total drones of the generation just
+        flown.  Children are then placed so that wavefronts are homogeneous in expected lifetime: sorted
+        by their first parent's flight time (descending, stable), the elite staying in slot 0.  A rollout
+        wavefront runs until its LAST drone has crashed, and in a GA generation most mutated children crash
+        early while the descendants of good flyers do not; mixed at random, nearly every wavefront holds a
+        long flyer.  The placement only permutes slots (a child's parents, cuts and mutation draws are keyed
+        by the child, ld_ga_breed's `order`), so the set of children -- and the multiset of their fitness --
+        is exactly what the unsorted step produces; the reference draws parents uniformly and attaches no
+        meaning to list positions beyond slot 0 (evolve/util.py:5-27, evolve/evolution.py:89-107).
+
+        slot_of: optional int64 device tensor [n_total]: the genome slot that holds the drone with canonical
+        index i.  Selection always works on canonical indices (fitness_all is then in canonical order and the
+        selected parents are translated to slots through it), which keeps a whole GA run independent of how
+        earlier generations were placed.  After the call, last_order holds this shard's placement
+        (slot -> local child index) or None."""
         torch = _torch()
         if self.n % 2:
             raise ValueError("the generation step pairs slots (i, i+1): the shard size must be even")
@@ -326,7 +407,17 @@ class Population:
         lib = _native.lib()
         _native.check(lib.ld_ga_select(C.byref(ga), C.byref(self.spec), self._ptr(fitness_all), n_total, child_begin,
                                        self.n, self._ptr(parents), self._ptr(cuts), self._stream()), "ld_ga_select")
+        if slot_of is not None:                                              # canonical parent ids -> genome slots
+            parents = slot_of.to(self.device)[parents.long()].to(torch.int32).contiguous()
         self.last_parents = parents
+        order = None
+        if lifetimes is not None and self.n > 2:
+            life = lifetimes.to(device=self.device).long()[parents.long()]
+            if elite is not None and child_begin == 0:
+                life = life.clone()
+                life[0] = torch.iinfo(torch.int64).max                       # the elite keeps slot 0
+            order = torch.sort(life, descending=True, stable=True).indices.to(torch.int32).contiguous()
+        self.last_order = order
         if fetch_parents is not None:
             src, parents = fetch_parents(parents)
             src, parents = src.contiguous(), parents.to(device=self.device, dtype=torch.int32).contiguous()
@@ -336,7 +427,7 @@ class Population:
             elite = elite.to(device=self.device, dtype=self.dtype).contiguous()
         _native.check(self._fn("ld_ga_breed")(C.byref(ga), C.byref(self.spec), self._ptr(src), n_per_segment, n_segments,
                                               self._ptr(parents), self._ptr(cuts), self._ptr(elite), child_begin, self.n,
-                                              self._ptr(children), self._stream()), "ld_ga_breed")
+                                              self._ptr(order), self._ptr(children), self._stream()), "ld_ga_breed")
         self.genomes = children
         self.last_cuts = cuts
 

@@ -315,3 +315,65 @@ def test_sharded_population_equals_unsharded(Population, torch, tmp_path, name, 
         assert got.shape == want.shape and np.array_equal(got, want), (name, r)
     res = whole.results()
     assert res["crashed"].any() and not res["crashed"].all() and res["coins"].max() >= 1
+
+
+# ------------------------------------------------------------------------------------------- lifetime-sorted placement
+def test_lifetime_sorted_placement_is_the_same_ga_run(Population, torch):
+    """DeviceEvolution places children so that wavefronts are homogeneous in expected lifetime (sorted by the
+    first parent's flight time).  The GA works on canonical indices, so the run must be THE SAME run with and
+    without the placement: identical best / global-best history, identical multiset of (reward, flight time,
+    coins) in every generation, the elite in slot 0 -- and the work a rollout does (sum over 8-drone groups of
+    the longest flight in the group, what the resident engine pays) must drop."""
+    from learning_drones_amd.parallel import DeviceEvolution, ShardedPopulation
+    n, hidden, T, gens = 4096, (16, 16), 600, 5
+    genes = _hover_genes(hidden, n, sigma=0.02, seed=8)                   # a population on the edge: some fly, many crash
+    runs = {}
+    for pack in (False, True):
+        pop = ShardedPopulation(n, hidden)
+        pop.local.set_genomes(genes)
+        evo = DeviceEvolution(pop, seed=11, pack_by_lifetime=pack)
+        per_gen, cost = [], []
+        for g in range(gens):
+            best, gbest, rec = evo.step(T)
+            rows = rec[:, :3].cpu().numpy()
+            per_gen.append(rows[np.lexsort(rows.T[::-1])])
+            life = rec[:, 1].cpu().numpy().reshape(-1, 8)
+            cost.append(int(life.max(axis=1).sum()) * 8)
+            if g > 0 and evo.elite is not None:
+                assert torch.equal(pop.local.genome_of(0), evo.elite)     # the elite sits in slot 0 of the new generation
+        runs[pack] = (list(evo.history), per_gen, cost)
+    assert runs[False][0] == runs[True][0]
+    for a, b in zip(runs[False][1], runs[True][1]):
+        assert np.array_equal(a, b)
+    # generation 0 is placed as given; from generation 1 on the sorted placement does less masked work
+    plain, packed = sum(runs[False][2][1:]), sum(runs[True][2][1:])
+    assert packed < 0.97 * plain, (plain, packed)            # measured: -8 % (a child's lifetime barely follows its parent's)
+
+
+@pytest.mark.parametrize("hidden,n,T", [((32, 32), 3000, 1500), ((16, 16), 1030, 2000), ((64, 64, 64), 300, 700), ((10, 10), 9, 300)])
+def test_compacting_rollout_is_bit_identical(Population, torch, hidden, n, T):
+    """Population.fly(engine="resident", compact=True) re-packs the drones still flying between segments
+    of the episode; every drone still executes its own timesteps with its own genome, so final states,
+    integer bookkeeping and records equal the plain rollout bit for bit -- on a population where most
+    drones crash at scattered times, a few fly the whole episode, and some crash into a wall."""
+    from test_gpu_parity import _mixed_genomes
+    spec, genes, cls = _mixed_genomes(hidden, n, seed=n)
+    rng = np.random.default_rng(1)
+    genes[cls == 1] += rng.normal(0, 0.02, genes[cls == 1].shape)          # marginal flyers: crash at scattered times
+    genes = genes.astype(np.float32).astype(np.float64)
+    walls = np.array([[3.0, 3.0, 8.0, 4.5, 7.0, 12.0]])
+    out = []
+    for kw in (dict(engine="step"), dict(engine="resident"), dict(engine="resident", compact=True)):
+        pop = Population(n, hidden, walls=walls)
+        pop.set_genomes(genes)
+        pop.fly(T, **kw)
+        out.append((pop.fstate.clone(), pop.istate.clone(), pop.records.clone()))
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            assert torch.equal(a, b)
+    life = (out[0][1][2] >> 1).cpu().numpy()
+    assert (life < T).mean() > 0.3 and (life == T).any()
+    # a population that is dead from the start, and one in which nobody dies, take the same path
+    pop = Population(64, hidden)
+    pop.fly(50, engine="resident", compact=True)                           # zero genomes: everyone climbs, nobody crashes
+    assert not pop.results()["crashed"].any()

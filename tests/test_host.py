@@ -156,10 +156,10 @@ def test_argument_validation_without_gpu(lib):
         assert getattr(lib, f"ld_genomes_pack_{sfx}")(fake, 10, fake, 4, 20, None) == SIZE                       # row stride < P
         assert getattr(lib, f"ld_genomes_unpack_{sfx}")(odd, fake, 20, 4, 20, None) == ALIGN
         breed = getattr(lib, f"ld_ga_breed_{sfx}")
-        assert breed(C.byref(ga), C.byref(spec), fake, 8, 1, fake, fake, None, 0, 7, vp(0x2000), None) == SIZE   # odd children
-        assert breed(C.byref(ga), C.byref(spec), fake, 8, 1, fake, fake, None, 0, 8, fake, None) == SIZE         # dst aliases src
-        assert breed(C.byref(ga), C.byref(spec), fake, 8, 1, fake, fake, None, 0, 0, fake, None) == OK
-        assert breed(None, C.byref(spec), fake, 8, 1, fake, fake, None, 0, 8, vp(0x2000), None) == NULL
+        assert breed(C.byref(ga), C.byref(spec), fake, 8, 1, fake, fake, None, 0, 7, None, vp(0x2000), None) == SIZE   # odd children
+        assert breed(C.byref(ga), C.byref(spec), fake, 8, 1, fake, fake, None, 0, 8, None, fake, None) == SIZE         # dst aliases src
+        assert breed(C.byref(ga), C.byref(spec), fake, 8, 1, fake, fake, None, 0, 0, None, fake, None) == OK
+        assert breed(None, C.byref(spec), fake, 8, 1, fake, fake, None, 0, 8, None, vp(0x2000), None) == NULL
         pid = getattr(lib, f"ld_pid_episode_{sfx}")
         assert pid(C.byref(sim), fake, fake, 0, 1.0, 1000, 100, fake, fake, fake, fake, None, 4, None) == SIZE   # no coins
         assert pid(C.byref(sim), None, None, 4, 1.0, 1000, 100, None, None, None, None, None, 0, None) == OK
@@ -168,6 +168,26 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ld_ga_select(C.byref(ga), C.byref(spec), fake, 8, 4, 6, fake, fake, None) == SIZE                # children overrun
     assert lib.ld_ga_select(C.byref(ga), C.byref(spec), fake, 8, 0, 0, None, None, None) == OK
     assert lib.ld_ga_select(C.byref(ga), C.byref(spec), None, 8, 0, 8, fake, fake, None) == NULL
+    steps = lib.ld_fly_steps_f32                                 # multi-wavefront / multi-step fused launch
+    assert steps(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, 8, -1, 0, None) == SIZE
+    assert steps(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, 8, 4, 3, None) == SIZE      # waves not 0/1/2/4/8
+    assert steps(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, 0, 4, 8, None) == OK
+    assert steps(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, odd, fake, fake, 8, 4, 8, None) == ALIGN
+    assert steps(C.byref(sim), C.byref(ep), C.byref(MlpSpec.from_hidden((12,))), fake, None, fake, fake, fake, 8, 4, 0, None) == SPEC
+    ro = lib.ld_fly_rollout_steps_f32
+    assert ro(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, fake, 8, 10, -1, 0, None) == SIZE
+    assert ro(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, fake, 0, 10, 0, 0, None) == OK
+    k, w, m = C.c_int32(), C.c_int32(), C.c_int32()
+    geo = lambda h, n, T: (lib.ld_fly_rollout_geometry_f32(C.byref(MlpSpec.from_hidden(h)), n, T, C.byref(k), C.byref(w), C.byref(m)),
+                           k.value, w.value, m.value)
+    assert geo((32, 32), 65536, 2000) == (OK, 16, 2, 125) and geo((32, 32), 8192, 2000) == (OK, 16, 8, 125)
+    assert geo((32, 32), 32768, 4000) == (OK, 16, 4, 250) and geo((64, 64, 64), 131072, 4000) == (OK, 16, 1, 250)
+    assert geo((64, 64, 64), 8192, 100) == (OK, 16, 4, 7) and geo((12,), 1000, 50) == (OK, 1, 1, 50)
+    assert lib.ld_fly_rollout_geometry_f32(C.byref(spec), 8, 8, None, None, None) == NULL
+    for sfx in ("f32", "f64"):
+        acc = getattr(lib, f"ld_accelerations_{sfx}")
+        assert acc(C.byref(sim), fake, fake, fake, None, 4, None) == NULL and acc(C.byref(sim), None, None, None, None, -1, None) == SIZE
+    assert lib.ld_debug_force_generic(1) == 0 and lib.ld_debug_force_generic(0) == 1
     res = lib.ld_fly_rollout_resident_f32
     unsupported = MlpSpec.from_hidden((12,))                 # no unrolled / resident specialisation
     assert res(C.byref(sim), C.byref(ep), C.byref(unsupported), fake, None, fake, fake, fake, fake, 8, 10, None) == SPEC

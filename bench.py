@@ -275,14 +275,14 @@ def main():
     # and crashes within a few hundred steps; frozen blocks skip their gene traffic, so an episode
     # costs far less than N*T full drone-steps.  Informational (live drone-steps only are real work).
     random_pop = {}
-    engines = () if args.no_extras else (("step", "resident", "resident_compacting") if hidden in pop.local.RESIDENT_SPECS else ("step",))
+    engines = () if args.no_extras else (("step", "resident") if hidden in pop.local.RESIDENT_SPECS else ("step",))
     if engines:
         pop.local.init_genomes_reference(seed=7 + rank)
     for engine in engines:
         pop.local.reset()
         fence()
         q0 = time.perf_counter()
-        rec = pop.fly(T, engine=engine.split("_")[0], compact=engine.endswith("compacting"))
+        rec = pop.fly(T, engine=engine)
         fence()
         random_pop[engine + "_episode_ms"] = (time.perf_counter() - q0) * 1e3
     if engines:
@@ -398,7 +398,7 @@ def main():
             "generations_per_s": None if gen_error else n_gen / gen_dt,
             "generation": {"measured": n_gen, "includes": "rollout, record all-gather, elite, parent exchange (N>1), "
                            "device select+breed (evolve/util.py + Drone.mutate semantics), reset; rollout engine: "
-                           + evo.engine + (" with survivors re-packed between segments" if evo.compact else "")
+                           + evo.engine + " (work-queue resident kernel where available)"
                            + ", parent exchange: " + (evo.exchange if world > 1 else "local"),
                            "live_drone_step_fraction": gen_live, "error": gen_error,
                            "select_breed_ms": breed_ms, "select_breed_gbs": breed_gbs,

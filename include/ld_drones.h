@@ -285,40 +285,26 @@ int ld_fly_rollout_steps_f32(const ld_sim_params *sim, const ld_episode_params *
 int ld_fly_rollout_geometry_f32(const ld_mlp_spec *spec, int64_t n, int32_t timesteps,
                                 int32_t *steps_per_launch, int32_t *waves_per_block, int32_t *n_launches);
 
-/* fly(drone, timesteps) with the genome RESIDENT in registers for the whole episode (float32):
- * ONE launch runs all `timesteps` iterations; each drone owns L lanes of a wavefront that share its
- * neurons, so the genes are read from HBM once per episode instead of once per step.  Same
- * arithmetic, bit-identical results to ld_fly_rollout_f32.  Available for the layer specs that have an
- * unrolled specialisation (8-10, 10-10, 16-16, 32-32, 64-64-64, 16, 32, 64, 8-8, 24-24, 48-48, 64-64,
- * 32-32-32); any other spec returns LD_ERR_SPEC (use ld_fly_rollout_f32, which runs every spec). */
+/* fly(drone, timesteps) with the genome RESIDENT in registers for the whole episode (float32): ONE launch
+ * runs all `timesteps` iterations; each drone owns L lanes of a wavefront that share its neurons, so the
+ * genes are read from HBM once per episode instead of once per step.  The wavefronts are persistent and
+ * pull drones from a work queue: a group of L lanes that has finished its drone (crashed, or `timesteps`
+ * done) stores it and takes the next index, so a population in which most drones crash early costs about
+ * its live drone-steps, not (lifetime of the longest flyer of each wavefront) x 64 / L.  `queue` is a
+ * device int32 the caller provides as workspace (the library allocates nothing); its content is
+ * irrelevant on entry.  Same arithmetic, bit-identical results to ld_fly_rollout_f32.  Available for the
+ * layer specs that have an unrolled specialisation (8-10, 10-10, 16-16, 32-32, 64-64-64, 16, 32, 64, 8-8,
+ * 24-24, 48-48, 64-64, 32-32-32); any other spec returns LD_ERR_SPEC (use ld_fly_rollout_f32). */
 int ld_fly_rollout_resident_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
                                 const double *coins, const double *walls, const float *genomes, float *fstate,
                                 int32_t *istate, ld_fitness_record *records, int64_t n, int32_t timesteps,
-                                void *stream);
+                                int32_t *queue, void *stream);
 
 /* `n_steps` loop iterations of the genome-resident kernel WITHOUT the finalize launch (the episode can be
- * continued, e.g. after compacting the survivors; finish with ld_fly_finalize_f32). */
+ * continued; finish with ld_fly_finalize_f32).  `queue` as in ld_fly_rollout_resident_f32. */
 int ld_fly_steps_resident_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
                               const double *coins, const double *walls, const float *genomes, float *fstate,
-                              int32_t *istate, int64_t n, int32_t n_steps, void *stream);
-
-/* Compaction of a population.  A wavefront of the rollout kernels runs until its LAST drone has crashed;
- * in a GA generation most children crash within a few hundred steps, so after a while most lanes of most
- * wavefronts are frozen.  ld_population_gather_* copies drone idx[j] (device int32[n_dst]) of a source
- * population (genome words + fstate + istate, n_src drones) into drone j of a destination population of
- * n_dst drones, which then flies on densely packed; ld_population_scatter_state_* writes the compact
- * population's state back to drones idx[j] of the home population (genomes never change during an
- * episode).  Source and destination arrays must not alias. */
-int ld_population_gather_f32(const ld_mlp_spec *spec, const int32_t *idx, int64_t n_dst, const float *src_genomes,
-                             const float *src_fstate, const int32_t *src_istate, int64_t n_src, float *dst_genomes,
-                             float *dst_fstate, int32_t *dst_istate, void *stream);
-int ld_population_gather_f64(const ld_mlp_spec *spec, const int32_t *idx, int64_t n_dst, const double *src_genomes,
-                             const double *src_fstate, const int32_t *src_istate, int64_t n_src, double *dst_genomes,
-                             double *dst_fstate, int32_t *dst_istate, void *stream);
-int ld_population_scatter_state_f32(const int32_t *idx, int64_t n_src, const float *src_fstate, const int32_t *src_istate,
-                                    float *dst_fstate, int32_t *dst_istate, int64_t n_dst, void *stream);
-int ld_population_scatter_state_f64(const int32_t *idx, int64_t n_src, const double *src_fstate, const int32_t *src_istate,
-                                    double *dst_fstate, int32_t *dst_istate, int64_t n_dst, void *stream);
+                              int32_t *istate, int64_t n, int32_t n_steps, int32_t *queue, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Generation step on the device: the GA operators of evolve/util.py:5-78 and
@@ -356,9 +342,9 @@ int ld_ga_select(const ld_ga_params *ga, const ld_mlp_spec *spec, const int32_t 
  * dst is the children's genome array (n_children drones, same blocked layout); it must not alias src.
  * order (device, int32[n_children], or NULL = identity) places child order[s] of this shard into genome
  * slot s.  A child's parents, cut points and random draws are keyed by the CHILD index, so every
- * placement produces the same set of children; the GA driver uses it to put children of long-lived
- * parents into the same wavefronts (a wavefront of the rollout kernels runs until its last drone has
- * crashed), keeping the elite in slot 0.  order must be a permutation of 0..n_children-1. */
+ * placement produces the same set of children; the GA driver sorts the children by the slot of their
+ * first parent (elite first), which makes the gather of 16-byte parent words below read neighbouring
+ * lines instead of 64 scattered ones per wavefront.  order must be a permutation of 0..n_children-1. */
 int ld_ga_breed_f32(const ld_ga_params *ga, const ld_mlp_spec *spec, const float *src, int64_t n_per_segment,
                     int32_t n_segments, const int32_t *parents, const int32_t *cuts, const float *elite,
                     int64_t child_begin, int64_t n_children, const int32_t *order, float *dst, void *stream);

@@ -27,8 +27,6 @@ EXPORTS = (
     "ld_ga_select", "ld_ga_breed_f32", "ld_ga_breed_f64", "ld_pid_episode_f32", "ld_pid_episode_f64",
     "ld_fly_rollout_resident_f32", "ld_debug_force_generic", "ld_accelerations_f32", "ld_accelerations_f64",
     "ld_fly_steps_f32", "ld_fly_rollout_steps_f32", "ld_fly_rollout_geometry_f32", "ld_fly_steps_resident_f32",
-    "ld_population_gather_f32", "ld_population_gather_f64", "ld_population_scatter_state_f32",
-    "ld_population_scatter_state_f64",
 )
 ABI_VERSION = 2
 
@@ -94,16 +92,13 @@ def _declare(h: C.CDLL) -> None:
     h.ld_fly_finalize_f64.argtypes = [ep, vp, vp, vp, vp, vp, i64, vp]
     h.ld_fly_rollout_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, i64, i32, vp]
     h.ld_fly_rollout_f64.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]
-    h.ld_fly_rollout_resident_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, i64, i32, vp]
+    h.ld_fly_rollout_resident_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]
     h.ld_fly_steps_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, i64, i32, i32, vp]
     h.ld_fly_rollout_steps_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
     h.ld_accelerations_f32.argtypes = [sim, vp, vp, vp, vp, i64, vp]
     h.ld_accelerations_f64.argtypes = [sim, vp, vp, vp, vp, i64, vp]
     h.ld_debug_force_generic.argtypes = [C.c_int]
-    h.ld_fly_steps_resident_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, i64, i32, vp]
-    for sfx in ("f32", "f64"):
-        getattr(h, f"ld_population_gather_{sfx}").argtypes = [spec, vp, i64, vp, vp, vp, i64, vp, vp, vp, vp]
-        getattr(h, f"ld_population_scatter_state_{sfx}").argtypes = [vp, i64, vp, vp, vp, vp, i64, vp]
+    h.ld_fly_steps_resident_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, i64, i32, vp, vp]
     pi32 = C.POINTER(C.c_int32)
     h.ld_fly_rollout_geometry_f32.argtypes = [spec, i64, i32, pi32, pi32, pi32]
     ga = C.POINTER(GaParams)

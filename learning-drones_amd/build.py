@@ -41,11 +41,23 @@ def _newest_input() -> float:
     return max(p.stat().st_mtime for p in HEADERS + [Path(__file__)])
 
 
+def _deps(obj: Path):
+    """Files the object was built from, read from the compiler's -MD dependency file (None if absent)."""
+    dep = obj.with_suffix(".d")
+    if not dep.exists():
+        return None
+    text = dep.read_text().replace("\\\n", " ")
+    return [Path(t) for t in text.split(":", 1)[1].split() if t.startswith(str(PKG_DIR.parent))]
+
+
 def _compile(src: Path, verbose: bool) -> Path:
     obj = OBJ_DIR / (src.stem + ".o")
-    if obj.exists() and obj.stat().st_mtime >= max(src.stat().st_mtime, _newest_input()):
-        return obj
-    cmd = [hipcc(), *FLAGS, "-c", str(src), "-o", str(obj)]
+    if obj.exists():
+        deps = _deps(obj)
+        newest = _newest_input() if deps is None else max([Path(__file__).stat().st_mtime] + [d.stat().st_mtime for d in deps if d.exists()])
+        if obj.stat().st_mtime >= max(src.stat().st_mtime, newest) and (deps is None or all(d.exists() for d in deps)):
+            return obj
+    cmd = [hipcc(), *FLAGS, "-MD", "-MF", str(obj.with_suffix(".d")), "-c", str(src), "-o", str(obj)]
     if verbose:
         print("[learning-drones_amd] " + " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -64,7 +76,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         return LIB
     OBJ_DIR.mkdir(exist_ok=True)
     if force:
-        for o in OBJ_DIR.glob("*.o"):
+        for o in list(OBJ_DIR.glob("*.o")) + list(OBJ_DIR.glob("*.d")):
             o.unlink()
     jobs = min(len(SOURCES), os.cpu_count() or 4, 8)
     with ThreadPoolExecutor(jobs) as pool:

@@ -13,7 +13,7 @@
 #endif
 
 int ld_resident_dispatch(const ld_sim_params*, const ld_episode_params*, const ld_mlp_spec*, const double*, const double*,
-                         const float*, float*, int32_t*, int64_t, int32_t, hipStream_t);          // ld_resident.hip
+                         const float*, float*, int32_t*, int64_t, int32_t, int32_t*, hipStream_t);   // ld_resident.hip
 
 using ld::blocks_for;
 using ld::check_launch;
@@ -300,37 +300,6 @@ int breed_impl(const ld_ga_params* ga, const ld_mlp_spec* spec, const Real* src,
     return check_launch("ga_breed_kernel");
 }
 
-template <typename Real>
-int gather_impl(const ld_mlp_spec* spec, const int32_t* idx, int64_t n_dst, const Real* src_genomes, const Real* src_fstate,
-                const int32_t* src_istate, int64_t n_src, Real* dst_genomes, Real* dst_fstate, int32_t* dst_istate, void* stream)
-{
-    const int64_t W = ld_mlp_words_per_drone(spec);
-    if (W < 0) return (int)W;
-    if (n_dst < 0 || n_src < 0) return LD_ERR_SIZE;
-    if (n_dst == 0) return LD_OK;
-    if (n_src == 0) return LD_ERR_SIZE;
-    if (!idx || !src_genomes || !src_fstate || !src_istate || !dst_genomes || !dst_fstate || !dst_istate) return LD_ERR_NULL;
-    if (!aligned16(src_genomes) || !aligned16(dst_genomes)) return LD_ERR_ALIGN;
-    if (src_genomes == dst_genomes || src_fstate == dst_fstate || src_istate == dst_istate) return LD_ERR_SIZE;
-    hipLaunchKernelGGL((ld::population_gather_kernel<Real>), dim3(blocks_for((W + LD_F_COUNT + LD_I_COUNT) * n_dst, 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), idx, n_dst, reinterpret_cast<const ld::GeneWord<Real>*>(src_genomes),
-                       src_fstate, src_istate, n_src, reinterpret_cast<ld::GeneWord<Real>*>(dst_genomes), dst_fstate, dst_istate, W);
-    return check_launch("population_gather_kernel");
-}
-
-template <typename Real>
-int scatter_impl(const int32_t* idx, int64_t n_src, const Real* src_fstate, const int32_t* src_istate, Real* dst_fstate,
-                 int32_t* dst_istate, int64_t n_dst, void* stream)
-{
-    if (n_dst < 0 || n_src < 0) return LD_ERR_SIZE;
-    if (n_src == 0) return LD_OK;
-    if (n_dst == 0) return LD_ERR_SIZE;
-    if (!idx || !src_fstate || !src_istate || !dst_fstate || !dst_istate) return LD_ERR_NULL;
-    hipLaunchKernelGGL((ld::population_scatter_state_kernel<Real>), dim3(blocks_for((int64_t)(LD_F_COUNT + LD_I_COUNT) * n_src, 256)),
-                       dim3(256), 0, static_cast<hipStream_t>(stream), idx, n_src, src_fstate, src_istate, dst_fstate, dst_istate, n_dst);
-    return check_launch("population_scatter_state_kernel");
-}
-
 template <typename Real, bool Faithful>
 int pid_impl(const ld_sim_params* sim, const Real* gains, const double* coins, int32_t n_coins, double coin_radius,
              int32_t coin_value, int32_t timesteps, Real* fstate, int32_t* score, int32_t* target, int32_t* steps,
@@ -352,33 +321,20 @@ extern "C" {
 
 int ld_fly_steps_resident_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,
                               const double* coins, const double* walls, const float* genomes, float* fstate,
-                              int32_t* istate, int64_t n, int32_t n_steps, void* stream)
+                              int32_t* istate, int64_t n, int32_t n_steps, int32_t* queue, void* stream)
 {
     if (n_steps < 0) return LD_ERR_SIZE;
     const int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
     if (rc || n == 0 || n_steps == 0) return rc;
-    return ld_resident_dispatch(sim, ep, spec, coins, walls, genomes, fstate, istate, n, n_steps,
+    if (!queue) return LD_ERR_NULL;
+    return ld_resident_dispatch(sim, ep, spec, coins, walls, genomes, fstate, istate, n, n_steps, queue,
                                 static_cast<hipStream_t>(stream));
 }
 
-int ld_population_gather_f32(const ld_mlp_spec* spec, const int32_t* idx, int64_t n_dst, const float* src_genomes,
-                             const float* src_fstate, const int32_t* src_istate, int64_t n_src, float* dst_genomes,
-                             float* dst_fstate, int32_t* dst_istate, void* stream)
-{ return gather_impl<float>(spec, idx, n_dst, src_genomes, src_fstate, src_istate, n_src, dst_genomes, dst_fstate, dst_istate, stream); }
-int ld_population_gather_f64(const ld_mlp_spec* spec, const int32_t* idx, int64_t n_dst, const double* src_genomes,
-                             const double* src_fstate, const int32_t* src_istate, int64_t n_src, double* dst_genomes,
-                             double* dst_fstate, int32_t* dst_istate, void* stream)
-{ return gather_impl<double>(spec, idx, n_dst, src_genomes, src_fstate, src_istate, n_src, dst_genomes, dst_fstate, dst_istate, stream); }
-int ld_population_scatter_state_f32(const int32_t* idx, int64_t n_src, const float* src_fstate, const int32_t* src_istate,
-                                    float* dst_fstate, int32_t* dst_istate, int64_t n_dst, void* stream)
-{ return scatter_impl<float>(idx, n_src, src_fstate, src_istate, dst_fstate, dst_istate, n_dst, stream); }
-int ld_population_scatter_state_f64(const int32_t* idx, int64_t n_src, const double* src_fstate, const int32_t* src_istate,
-                                    double* dst_fstate, int32_t* dst_istate, int64_t n_dst, void* stream)
-{ return scatter_impl<double>(idx, n_src, src_fstate, src_istate, dst_fstate, dst_istate, n_dst, stream); }
-
 int ld_fly_rollout_resident_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,
                                 const double* coins, const double* walls, const float* genomes, float* fstate,
-                                int32_t* istate, ld_fitness_record* records, int64_t n, int32_t timesteps, void* stream)
+                                int32_t* istate, ld_fitness_record* records, int64_t n, int32_t timesteps, int32_t* queue,
+                                void* stream)
 {
     if (!sim || !ep) return LD_ERR_NULL;
     int rc = check_spec(spec);
@@ -387,10 +343,12 @@ int ld_fly_rollout_resident_f32(const ld_sim_params* sim, const ld_episode_param
     if (n == 0) return LD_OK;
     rc = check_episode(ep, coins, walls);
     if (rc) return rc;
-    if (!genomes || !fstate || !istate) return LD_ERR_NULL;
+    if (!genomes || !fstate || !istate || !queue) return LD_ERR_NULL;
     if (!aligned16(genomes)) return LD_ERR_ALIGN;
-    rc = ld_resident_dispatch(sim, ep, spec, coins, walls, genomes, fstate, istate, n, timesteps,
-                              static_cast<hipStream_t>(stream));
+    if (timesteps > 0) {
+        rc = ld_resident_dispatch(sim, ep, spec, coins, walls, genomes, fstate, istate, n, timesteps, queue,
+                                  static_cast<hipStream_t>(stream));
+    }
     if (rc) return rc;
     return finalize_impl<float>(ep, coins, fstate, istate, records, nullptr, n, stream);
 }

@@ -306,42 +306,6 @@ genome_layout_kernel(Real* __restrict__ rows, const int64_t row_stride, GeneWord
     }
 }
 
-// Compaction of a population (live drones of a GA generation, see Population.fly(compact=True)): drone
-// idx[j] of the source becomes drone j of the destination, genome words and state.  One thread per
-// (word or state field, destination drone); destination stores are coalesced, source reads are 16-byte
-// (genes) / 4-byte (state) gathers.
-template <typename Real>
-__global__ void __launch_bounds__(256)
-population_gather_kernel(const int32_t* __restrict__ idx, const int64_t n_dst, const GeneWord<Real>* __restrict__ src_genomes,
-                         const Real* __restrict__ src_fstate, const int32_t* __restrict__ src_istate, const int64_t n_src,
-                         GeneWord<Real>* __restrict__ dst_genomes, Real* __restrict__ dst_fstate,
-                         int32_t* __restrict__ dst_istate, const int64_t W)
-{
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t rows = W + LD_F_COUNT + LD_I_COUNT;
-    if (t >= rows * n_dst) return;
-    const int64_t r = t / n_dst, j = t % n_dst;
-    const int64_t i = idx[j];
-    if (r < W) dst_genomes[word_index(j, r, W)] = src_genomes[word_index(i, r, W)];
-    else if (r < W + LD_F_COUNT) dst_fstate[(r - W) * n_dst + j] = src_fstate[(r - W) * n_src + i];
-    else dst_istate[(r - W - LD_F_COUNT) * n_dst + j] = src_istate[(r - W - LD_F_COUNT) * n_src + i];
-}
-
-// The way back: state of compact drone j to drone idx[j] of the home population (genomes do not change).
-template <typename Real>
-__global__ void __launch_bounds__(256)
-population_scatter_state_kernel(const int32_t* __restrict__ idx, const int64_t n_src, const Real* __restrict__ src_fstate,
-                                const int32_t* __restrict__ src_istate, Real* __restrict__ dst_fstate,
-                                int32_t* __restrict__ dst_istate, const int64_t n_dst)
-{
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (int64_t)(LD_F_COUNT + LD_I_COUNT) * n_src) return;
-    const int64_t r = t / n_src, j = t % n_src;
-    const int64_t i = idx[j];
-    if (r < LD_F_COUNT) dst_fstate[r * n_dst + i] = src_fstate[r * n_src + j];
-    else dst_istate[(r - LD_F_COUNT) * n_dst + i] = src_istate[(r - LD_F_COUNT) * n_src + j];
-}
-
 }  // namespace ld
 
 

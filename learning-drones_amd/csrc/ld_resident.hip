@@ -18,11 +18,11 @@ template <int L, int... H> static bool resident_matches(const ld_mlp_spec& s) { 
 
 int ld_resident_dispatch(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,
                          const double* coins, const double* walls, const float* genomes, float* fstate, int32_t* istate,
-                         int64_t n, int32_t timesteps, hipStream_t stream)
+                         int64_t n, int32_t timesteps, int32_t* queue, hipStream_t stream)
 {
 #define X(L, ...)                                                                                      \
     if (resident_matches<L, __VA_ARGS__>(*spec))                                                       \
-        return ld::launch_fly_resident<L, __VA_ARGS__>(sim, ep, coins, walls, genomes, fstate, istate, n, timesteps, stream);
+        return ld::launch_fly_resident<L, __VA_ARGS__>(sim, ep, coins, walls, genomes, fstate, istate, n, timesteps, queue, stream);
     LD_FOR_EACH_RESIDENT(X)
 #undef X
     return LD_ERR_SPEC;

@@ -18,6 +18,8 @@
 // Reference semantics are exactly fly_step_kernel's (flight/__init__.py:39-89); see ld_kernels.hpp.
 #pragma once
 
+#include <algorithm>
+
 #include "ld_kernels.hpp"
 
 namespace ld {
@@ -44,11 +46,19 @@ template <int L, int... H> struct ResidentLayout {
 #ifndef LD_RES_WAVES
 #define LD_RES_WAVES 1
 #endif
+// Persistent wavefronts with a work queue.  A group of L lanes flies ONE drone at a time and, when that
+// drone has crashed or finished its `timesteps`, stores it and takes the next drone index from a global
+// counter (one returning atomicAdd by the group's first lane, broadcast inside the group), reloading its
+// share of the new genome into the same registers.  The groups of a wavefront are therefore at different
+// timesteps of different drones; the instruction stream does not care.  Without the queue a wavefront runs
+// until the LAST of its 64 / L drones is done, and in a GA generation (most children crash within a few
+// hundred steps, a few fly the whole episode, scattered at random) that is ~2x the work of the live
+// drone-steps.  Every wavefront leaves its loop once the counter has passed n and its groups have drained.
 template <int L, int... H>
 __global__ void __launch_bounds__(64, LD_RES_WAVES)
 fly_resident_kernel(const SimT<float> sim, const EpT<float> ep, const double* __restrict__ coins,
                     const double* __restrict__ walls, const float* __restrict__ genomes, float* __restrict__ fstate,
-                    int32_t* __restrict__ istate, const int64_t n, const int32_t timesteps)
+                    int32_t* __restrict__ istate, const int64_t n, const int32_t timesteps, int32_t* __restrict__ queue)
 {
     using Lay = ResidentLayout<L, H...>;
     using Shape = typename Lay::Shape;
@@ -58,39 +68,54 @@ fly_resident_kernel(const SimT<float> sim, const EpT<float> ep, const double* __
     __shared__ float xch[2][G][MW + 4];                   // layer outputs, ping-pong, one padded row per drone
 
     const int lane = threadIdx.x, g = lane / L, l = lane % L;
-    const int64_t drone = (int64_t)blockIdx.x * G + g;
-    const bool valid = drone < n;
-    const int64_t i = valid ? drone : n - 1;
-
-    // ---- this lane's share of the genome -> registers (once per episode)
-    float genes[Lay::kGeneRegs];
-    static_for<0, Shape::n_layers>([&](auto lc) __attribute__((always_inline)) {
-        constexpr int layer = decltype(lc)::value;
-        constexpr int n_in = Shape::dims[layer], n_out = Shape::dims[layer + 1];
-        static_for<0, Lay::slots(layer)>([&](auto qc) __attribute__((always_inline)) {
-            constexpr int q = decltype(qc)::value;
-            const int j = l + q * L;
-            const int jj = j < n_out ? j : n_out - 1;                       // lanes without a neuron re-read the last row
-            static_for<0, n_in + 1>([&](auto kc) __attribute__((always_inline)) {
-                constexpr int k = decltype(kc)::value;
-                const int p = Shape::layer_offset(layer) + jj * (n_in + 1) + k;
-                genes[Lay::reg_offset(layer) + q * (n_in + 1) + k] = genomes[word_index(i, p >> 2, Shape::W) * 4 + (p & 3)];
-            });
-        });
-    });
-
-    int32_t status = istate[(int64_t)LD_I_STATUS * n + i];
-    int32_t reward = istate[(int64_t)LD_I_REWARD * n + i];
-    int32_t ncoll = istate[(int64_t)LD_I_COINS * n + i];
-    DroneRegs<float> d;
-    load_drone<float>(fstate, n, i, d);
     stage_tables<float>(tab, ep, coins, walls);
     __syncthreads();
 
-    bool dead = (status & 1) || !valid;
-    int32_t flight_time = status >> 1;
-    for (int32_t t = 0; t < timesteps; ++t) {
-        if (__all(dead)) break;
+    float genes[Lay::kGeneRegs];
+    DroneRegs<float> d;
+    int32_t reward = 0, ncoll = 0, flight_time = 0, t_left = 0;
+    bool crashed_state = false;
+    int64_t drone = (int64_t)blockIdx.x * G + g;          // first assignment; the queue hands out gridDim.x * G, ...
+    bool active = drone < n && timesteps > 0;
+    bool load = active;
+
+    while (true) {                                        // one pass per (re)load of the wavefront's genomes
+        {
+            // ---- this lane's share of its new drone's genome -> registers (exec-masked loads: the groups that
+            // keep their drone keep their genes)
+            // (a laundered copy of the lane's neuron index: the per-gene address offsets depend only on it, so
+            // the compiler would otherwise compute all 2 x kGeneRegs of them ONCE, before the loop, and keep them
+            // in registers for the whole kernel -- that, not the genes, is what overflowed the register file)
+            int lv = l;
+            asm volatile("" : "+v"(lv));
+            if (load) static_for<0, Shape::n_layers>([&](auto lc) __attribute__((always_inline)) {
+                constexpr int layer = decltype(lc)::value;
+                constexpr int n_in = Shape::dims[layer], n_out = Shape::dims[layer + 1];
+                static_for<0, Lay::slots(layer)>([&](auto qc) __attribute__((always_inline)) {
+                    constexpr int q = decltype(qc)::value;
+                    const int j = lv + q * L;
+                    const int jj = j < n_out ? j : n_out - 1;                       // lanes without a neuron re-read the last row
+                    static_for<0, n_in + 1>([&](auto kc) __attribute__((always_inline)) {
+                        constexpr int k = decltype(kc)::value;
+                        const int p = Shape::layer_offset(layer) + jj * (n_in + 1) + k;
+                        genes[Lay::reg_offset(layer) + q * (n_in + 1) + k] = genomes[word_index(drone, p >> 2, Shape::W) * 4 + (p & 3)];
+                    });
+                });
+            });
+            if (load) {
+                const int32_t status = istate[(int64_t)LD_I_STATUS * n + drone];
+                reward = istate[(int64_t)LD_I_REWARD * n + drone];
+                ncoll = istate[(int64_t)LD_I_COINS * n + drone];
+                load_drone<float>(fstate, n, drone, d);
+                crashed_state = (status & 1) != 0;
+                flight_time = status >> 1;
+                t_left = timesteps;
+            }
+            load = false;
+        }
+        if (!__any(active)) break;
+
+        do {                                              // timesteps until some group needs a new drone
         // ---- flight/__init__.py:41-52, :79 (identical to fly_step_kernel)
         int32_t r = reward + ep.reward_time;
         int32_t nc = ncoll;
@@ -141,7 +166,8 @@ fly_resident_kernel(const SimT<float> sim, const EpT<float> ep, const double* __
         });
         LD_RES_SYNC();                                     // the next step's first layer reuses buffer 0
 
-        if (!dead) {                                       // commit, as fly_step_kernel does
+        const bool stepping = active && !crashed_state;    // commit, as fly_step_kernel does
+        if (stepping) {
 #pragma unroll
             for (int k = 0; k < 12; ++k) d.s[k] = e.s[k];
 #pragma unroll
@@ -153,25 +179,52 @@ fly_resident_kernel(const SimT<float> sim, const EpT<float> ep, const double* __
             reward = r;
             ncoll = nc;
             flight_time += 1;
-            dead = crashed;
+            crashed_state = crashed;
         }
-    }
-    if (valid && l == 0) {
-        store_drone<float>(fstate, n, i, d);
-        istate[(int64_t)LD_I_REWARD * n + i] = reward;
-        istate[(int64_t)LD_I_COINS * n + i] = ncoll;
-        istate[(int64_t)LD_I_STATUS * n + i] = 2 * flight_time + (dead ? 1 : 0);
+        t_left -= 1;
+
+        // ---- drones that are done: store them, take the next index from the queue
+        const bool done = active && (crashed_state || t_left <= 0);
+        if (__any(done)) {
+            int32_t next = 0;
+            if (done && l == 0) {
+                store_drone<float>(fstate, n, drone, d);
+                istate[(int64_t)LD_I_REWARD * n + drone] = reward;
+                istate[(int64_t)LD_I_COINS * n + drone] = ncoll;
+                istate[(int64_t)LD_I_STATUS * n + drone] = 2 * flight_time + (crashed_state ? 1 : 0);
+                next = atomicAdd(queue, 1);
+            }
+            next = __shfl(next, g * L);                   // the group's first lane holds the answer
+            if (done) {
+                drone = (int64_t)gridDim.x * G + next;
+                active = drone < n;
+                load = active;
+            }
+        }
+        } while (!__any(load) && __any(active));
     }
 }
 
 template <int L, int... H>
 int launch_fly_resident(const ld_sim_params* sim, const ld_episode_params* ep, const double* coins, const double* walls,
-                        const float* genomes, float* fstate, int32_t* istate, int64_t n, int32_t timesteps, hipStream_t stream)
+                        const float* genomes, float* fstate, int32_t* istate, int64_t n, int32_t timesteps, int32_t* queue,
+                        hipStream_t stream)
 {
     constexpr int G = 64 / L;
-    hipLaunchKernelGGL((fly_resident_kernel<L, H...>), dim3(blocks_for(n, G)), dim3(64), 0, stream, make_sim<float>(*sim),
-                       make_ep<float>(*ep), coins, walls,
-                       genomes, fstate, istate, n, timesteps);
+    // persistent grid: as many wavefronts as the chip holds at once (or fewer, for a small population)
+    static int resident_blocks = 0;
+    if (resident_blocks == 0) {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fly_resident_kernel<L, H...>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            cus = 256;
+        resident_blocks = per_cu * cus;
+    }
+    const unsigned blocks = (unsigned)std::min<int64_t>(blocks_for(n, G), resident_blocks);
+    hipError_t e = hipMemsetAsync(queue, 0, sizeof(int32_t), stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(queue)");
+    hipLaunchKernelGGL((fly_resident_kernel<L, H...>), dim3(blocks), dim3(64), 0, stream, make_sim<float>(*sim),
+                       make_ep<float>(*ep), coins, walls, genomes, fstate, istate, n, timesteps, queue);
     return check_launch("fly_resident_kernel");
 }
 

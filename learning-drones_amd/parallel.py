@@ -12,7 +12,7 @@ against a ~0.2 s rollout, so nothing is bucketed or overlapped.
 """
 from __future__ import annotations
 
-from typing import Tuple
+from typing import Optional, Tuple
 
 import numpy as np
 
@@ -163,15 +163,16 @@ class DeviceEvolution:
     single-GPU rehearsals only; it is unverified on RCCL until a multi-GPU record exists."""
 
     def __init__(self, population: "ShardedPopulation", ga=None, seed: int = 0, engine: str = "auto",
-                 exchange: str = "alltoall", pack_by_lifetime: bool = True, compact: bool = True):
+                 exchange: str = "alltoall", place: Optional[str] = "parent"):
         from .params import GaParams
         if exchange not in ("alltoall", "allgather"):
             raise ValueError("exchange must be 'alltoall' or 'allgather'")
         self.pop = population
         self.engine = engine
         self.exchange = exchange
-        self.pack_by_lifetime = pack_by_lifetime       # Population.breed(lifetimes=...): same children, lifetime-sorted slots
-        self.compact = compact                         # Population.fly(compact=True): survivors re-packed between segments
+        if place not in (None, "parent", "lifetime"):
+            raise ValueError("place must be None, 'parent' or 'lifetime'")
+        self.place = place                             # Population.breed: where the children go (same children either way)
         self._alltoall_checked = False
         self.ga = ga if ga is not None else GaParams.reference(seed=seed)
         self.generation = 0
@@ -196,14 +197,15 @@ class DeviceEvolution:
         """One generation.  Returns (best_score, global_best_score, records)."""
         import torch
         pop = self.pop
-        records = pop.fly(timesteps, engine=self.engine, compact=self.compact)   # rollout + all-gather of records (slot order)
+        records = pop.fly(timesteps, engine=self.engine)              # rollout + all-gather of records (slot order)
         # The GA itself works on CANONICAL drone indices: child c of a generation is drone c of the next
         # one wherever its genome was placed (slot_of), so a run is the same run with or without the
-        # lifetime-sorted placement below.
+        # sorted placement of the children below.
         slot_of = self.slot_of
         canon = records if slot_of is None else records[slot_of]
         fitness = canon[:, 0].contiguous()
-        lifetimes = records[:, 1].contiguous() if self.pack_by_lifetime else None      # indexed by slot, as breed() reads it
+        lifetimes = records[:, 1].contiguous() if self.place == "lifetime" else None   # indexed by slot, as breed() reads it
+        place = "parent" if self.place == "parent" else None
         best_score = int(fitness.max().item())
         # FIRST maximum, as np.argmax (evolution.py:77); torch.argmax does not promise which of several
         # equal maxima it returns, and every rank must name the same owner for the broadcast below
@@ -234,13 +236,13 @@ class DeviceEvolution:
             self._alltoall_checked = True
         if pop.world > 1 and self.exchange == "alltoall":
             # only the selected parents travel (~1/W of an all-gather)
-            pop.local.breed(fitness, self.ga, elite=self.elite, child_begin=pop.begin, lifetimes=lifetimes, slot_of=slot_of,
+            pop.local.breed(fitness, self.ga, elite=self.elite, child_begin=pop.begin, lifetimes=lifetimes, slot_of=slot_of, place=place,
                             fetch_parents=lambda parents: exchange_parent_genomes(pop.local.genomes, pop.local.n, parents,
                                                                                   DistComm(pop.group)))
         else:
             src, n_per_segment, n_segments = self._gather_genomes()
             pop.local.breed(fitness, self.ga, elite=self.elite, child_begin=pop.begin, src=src,
-                            n_per_segment=n_per_segment, n_segments=n_segments, lifetimes=lifetimes, slot_of=slot_of)
+                            n_per_segment=n_per_segment, n_segments=n_segments, lifetimes=lifetimes, slot_of=slot_of, place=place)
         # where each child went: local placement -> global canonical-index -> slot map for the next generation
         order = pop.local.last_order
         if order is None:

@@ -77,6 +77,7 @@ class Population:
         self.genomes = torch.zeros((self.n_blocks, W, GENOME_BLOCK, 4), dtype=self.dtype, device=dev)
         self.records = torch.zeros((n, 4), dtype=torch.int32, device=dev)          # ld_fitness_record[n]
         self.distance = torch.zeros((n,), dtype=torch.float64, device=dev) if precision == "f64" else None
+        self.queue = torch.zeros((1,), dtype=torch.int32, device=dev)          # work-queue counter of the resident kernel
         self.coins_dev = torch.from_numpy(coins).to(dev)
         self.walls_dev = torch.from_numpy(walls).to(dev) if len(walls) else None
         self._finalized = False
@@ -233,81 +234,21 @@ class Population:
     RESIDENT_SPECS = ((8, 10), (10, 10), (16, 16), (32, 32), (64, 64, 64), (16,), (32,), (64,), (8, 8), (24, 24),
                       (48, 48), (64, 64), (32, 32, 32))
 
-    # ------------------------------------------------------------------ compaction (GA generations)
-    COMPACT_FIRST_SEGMENT = 64        # timesteps before the first look at who is still flying
-    COMPACT_MAX_SEGMENT = 512
-    COMPACT_KEEP_ABOVE = 0.75         # re-pack when fewer than this share of the working set is alive
-
-    def _fly_resident_compacting(self, timesteps: int):
-        """fly() on the genome-resident kernel with the survivors re-packed between segments.
-
-        A wavefront of the rollout kernels runs until its LAST drone has crashed.  In a GA generation most
-        mutated children crash within a few hundred steps while a few fly the whole episode, and a child's
-        lifetime is not predictable from its parents' (measured: sorting children by parent lifetime cuts the
-        masked work by 8 %), so after a while nearly every wavefront carries one long flyer and seven frozen
-        lanes.  Here the episode runs in segments (64, 128, 256, 512, 512 ... timesteps); after a segment the
-        drones still flying are gathered -- genome words and state, ld_population_gather_* -- into a dense
-        working population that flies the next segment, and their state goes back to their home slots
-        (ld_population_scatter_state_*).  Every drone still executes exactly its own timesteps with its own
-        genome, so records and final states are bit-identical to the uncompacted rollout (tested)."""
-        torch = _torch()
-        lib = _native.lib()
-        T = int(timesteps)
-        gather, scatter = self._fn("ld_population_gather"), self._fn("ld_population_scatter_state")
-        w_genomes, w_fstate, w_istate, w_n, idx = self.genomes, self.fstate, self.istate, self.n, None
-        t, seg = 0, self.COMPACT_FIRST_SEGMENT
-        while t < T and w_n > 0:
-            k = min(seg, T - t)
-            _native.check(lib.ld_fly_steps_resident_f32(C.byref(self.sim), C.byref(self.episode), C.byref(self.spec),
-                                                        self._ptr(self.coins_dev), self._ptr(self.walls_dev), self._ptr(w_genomes),
-                                                        self._ptr(w_fstate), self._ptr(w_istate), w_n, k, self._stream()),
-                          "ld_fly_steps_resident_f32")
-            t += k
-            seg = min(2 * seg, self.COMPACT_MAX_SEGMENT)
-            if t >= T:
-                break
-            alive = (w_istate[I_STATUS] & 1) == 0
-            n_alive = int(alive.sum().item())                                # the one host round trip per segment
-            if n_alive > self.COMPACT_KEEP_ABOVE * w_n:
-                continue
-            if idx is not None:                                              # everything the working set did goes home first
-                _native.check(scatter(self._ptr(idx), w_n, self._ptr(w_fstate), self._ptr(w_istate), self._ptr(self.fstate),
-                                      self._ptr(self.istate), self.n, self._stream()), "ld_population_scatter_state")
-            if n_alive == 0:
-                w_n, idx = 0, None
-                break
-            keep = alive.nonzero().flatten().to(torch.int32)
-            blocks = (n_alive + GENOME_BLOCK - 1) // GENOME_BLOCK
-            n_genomes = torch.empty((blocks, self.W, GENOME_BLOCK, 4), dtype=self.dtype, device=self.device)
-            n_fstate = torch.empty((F_COUNT, n_alive), dtype=self.dtype, device=self.device)
-            n_istate = torch.empty((I_COUNT, n_alive), dtype=torch.int32, device=self.device)
-            _native.check(gather(C.byref(self.spec), self._ptr(keep), n_alive, self._ptr(w_genomes), self._ptr(w_fstate),
-                                 self._ptr(w_istate), w_n, self._ptr(n_genomes), self._ptr(n_fstate), self._ptr(n_istate),
-                                 self._stream()), "ld_population_gather")
-            idx = keep if idx is None else idx[keep.long()].contiguous()
-            w_genomes, w_fstate, w_istate, w_n = n_genomes, n_fstate, n_istate, n_alive
-        if idx is not None and w_n > 0:
-            _native.check(scatter(self._ptr(idx), w_n, self._ptr(w_fstate), self._ptr(w_istate), self._ptr(self.fstate),
-                                  self._ptr(self.istate), self.n, self._stream()), "ld_population_scatter_state")
-        self.finalize()
-        return self.records
-
     def fly(self, timesteps: int = 2500, engine: str = "step", steps_per_launch: Optional[int] = None,
-            waves_per_block: int = 0, compact: bool = False):
+            waves_per_block: int = 0):
         """fly(drone, timesteps) for every drone, enqueued from C on the current stream.  Returns the
         device tensor of result records ([n, 4] int32 view of ld_fitness_record); see results().
 
-        engine="step": `timesteps` launches of the fused step kernel (one launch advances the whole
-        population one timestep; genes streamed from HBM every step) + finalize.  steps_per_launch /
-        waves_per_block (float32, unrolled specs) make the launch geometry explicit (ld_fly_rollout_steps_f32):
-        by default a block's 64 drones get as many wavefronts as fill the chip, and only shards too small
-        to amortise a kernel boundary take several timesteps per launch.
-        engine="resident" (float32, specs RESIDENT_SPECS): one launch for the whole episode with the
-        genome held in registers (ld_fly_rollout_resident_f32); bit-identical results, 3-6x faster.
-        engine="auto": resident where available, else step.
-        compact=True (resident engine): re-pack the drones still flying between segments of the episode
-        (_fly_resident_compacting) -- for populations in which most drones crash early (GA generations);
-        bit-identical results."""
+        engine="step": the fused step kernel, genes streamed from memory every timestep, + finalize.  By
+        default (float32, unrolled specs) a launch advances the population 16 timesteps with the drone
+        state in registers in between, and a genome block's 64 drones get as many wavefronts as fill the
+        chip; steps_per_launch / waves_per_block make that geometry explicit (ld_fly_rollout_steps_f32;
+        steps_per_launch=1 is one launch per timestep).  Results do not depend on the geometry.
+        engine="resident" (float32, specs RESIDENT_SPECS): one launch for the whole episode with the genome
+        held in registers and drones handed to lane groups from a work queue (ld_fly_rollout_resident_f32);
+        bit-identical results, 3-6x faster, and a population in which most drones crash early costs about
+        its live drone-steps.
+        engine="auto": resident where available, else step."""
         if self._finalized:
             raise RuntimeError("episode already finalized; reset() first")
         args = [C.byref(self.sim), C.byref(self.episode), C.byref(self.spec), self._ptr(self.coins_dev),
@@ -318,9 +259,7 @@ class Population:
         if engine == "resident":
             if self.precision != "f32" or self.spec.hidden_widths not in self.RESIDENT_SPECS:
                 raise ValueError("the resident engine is float32 and covers the specs " + str(self.RESIDENT_SPECS))
-            if compact and self.n > 0:
-                return self._fly_resident_compacting(timesteps)
-            args += [self.n, int(timesteps), self._stream()]
+            args += [self.n, int(timesteps), self._ptr(self.queue), self._stream()]
             _native.check(_native.lib().ld_fly_rollout_resident_f32(*args), "ld_fly_rollout_resident_f32")
             self._finalized = True
             return self.records
@@ -368,7 +307,7 @@ class Population:
 
     def breed(self, fitness_all, ga: GaParams, *, elite=None, child_begin: int = 0, src=None,
               n_per_segment: Optional[int] = None, n_segments: int = 1, fetch_parents=None, lifetimes=None,
-              slot_of=None) -> None:
+              slot_of=None, place: Optional[str] = None) -> None:
         """Replace this population's genomes by the next generation (evolve/util.py:5-78 +
         drone/drone.py:167-172 + the elitism of evolve/evolution.py:105-107), on the device.
 
@@ -379,15 +318,15 @@ class Population:
         global child 0, or None; fetch_parents: optional callable(parents_global) -> (src genome array,
         parents re-indexed into it) used by the multi-GPU all-to-all exchange (parallel.py).
 
-        lifetimes: optional int32 device tensor, flight_time of ALL n_total drones of the generation just
-        flown.  Children are then placed so that wavefronts are homogeneous in expected lifetime: sorted
-        by their first parent's flight time (descending, stable), the elite staying in slot 0.  A rollout
-        wavefront runs until its LAST drone has crashed, and in a GA generation most mutated children crash
-        early while the descendants of good flyers do not; mixed at random, nearly every wavefront holds a
-        long flyer.  The placement only permutes slots (a child's parents, cuts and mutation draws are keyed
-        by the child, ld_ga_breed's `order`), so the set of children -- and the multiset of their fitness --
-        is exactly what the unsorted step produces; the reference draws parents uniformly and attaches no
-        meaning to list positions beyond slot 0 (evolve/util.py:5-27, evolve/evolution.py:89-107).
+        Placement of the children (ld_ga_breed's `order`; a child's parents, cuts and mutation draws are keyed
+        by the child, so any placement produces the same set of children, and the reference attaches no
+        meaning to list positions beyond slot 0: evolve/util.py:5-27, evolve/evolution.py:89-107):
+        place="parent" sorts the children by the slot of their first parent, which turns the kernel's gather
+        of 16-byte parent words from 64 scattered 1 KiB lines per wavefront into a read of one or two
+        neighbouring lines; lifetimes (int32 device tensor, flight_time of ALL n_total drones of the
+        generation just flown) sorts them by that parent's flight time instead, longest first -- measured to
+        be worth 8 % of a rollout's masked work (a child's lifetime barely follows its parent's), and nothing
+        since the resident kernel hands drones out from a work queue.  The elite stays in slot 0 either way.
 
         slot_of: optional int64 device tensor [n_total]: the genome slot that holds the drone with canonical
         index i.  Selection always works on canonical indices (fitness_all is then in canonical order and the
@@ -411,12 +350,14 @@ class Population:
             parents = slot_of.to(self.device)[parents.long()].to(torch.int32).contiguous()
         self.last_parents = parents
         order = None
-        if lifetimes is not None and self.n > 2:
-            life = lifetimes.to(device=self.device).long()[parents.long()]
+        if self.n > 2 and (lifetimes is not None or place == "parent"):
+            if lifetimes is not None:                                         # longest-lived first
+                key = -lifetimes.to(device=self.device).long()[parents.long()]
+            else:                                                             # neighbours in the gather
+                key = parents.long().clone()
             if elite is not None and child_begin == 0:
-                life = life.clone()
-                life[0] = torch.iinfo(torch.int64).max                       # the elite keeps slot 0
-            order = torch.sort(life, descending=True, stable=True).indices.to(torch.int32).contiguous()
+                key[0] = torch.iinfo(torch.int64).min                         # the elite keeps slot 0
+            order = torch.sort(key, stable=True).indices.to(torch.int32).contiguous()
         self.last_order = order
         if fetch_parents is not None:
             src, parents = fetch_parents(parents)

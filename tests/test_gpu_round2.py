@@ -317,45 +317,47 @@ def test_sharded_population_equals_unsharded(Population, torch, tmp_path, name, 
     assert res["crashed"].any() and not res["crashed"].all() and res["coins"].max() >= 1
 
 
-# ------------------------------------------------------------------------------------------- lifetime-sorted placement
-def test_lifetime_sorted_placement_is_the_same_ga_run(Population, torch):
-    """DeviceEvolution places children so that wavefronts are homogeneous in expected lifetime (sorted by the
-    first parent's flight time).  The GA works on canonical indices, so the run must be THE SAME run with and
-    without the placement: identical best / global-best history, identical multiset of (reward, flight time,
-    coins) in every generation, the elite in slot 0 -- and the work a rollout does (sum over 8-drone groups of
-    the longest flight in the group, what the resident engine pays) must drop."""
+# ------------------------------------------------------------------------------------------- placement of the children
+def test_child_placement_is_the_same_ga_run(Population, torch):
+    """DeviceEvolution places the children of a generation sorted by the slot of their first parent (gather
+    locality of the breed kernel) or, optionally, by that parent's flight time.  The GA works on canonical
+    indices and every draw is keyed by the child, so the run must be THE SAME run whatever the placement:
+    identical best / global-best history and an identical multiset of (reward, flight time, coins) in every
+    generation, with the elite in slot 0."""
     from learning_drones_amd.parallel import DeviceEvolution, ShardedPopulation
     n, hidden, T, gens = 4096, (16, 16), 600, 5
     genes = _hover_genes(hidden, n, sigma=0.02, seed=8)                   # a population on the edge: some fly, many crash
     runs = {}
-    for pack in (False, True):
+    for place in (None, "parent", "lifetime"):
         pop = ShardedPopulation(n, hidden)
         pop.local.set_genomes(genes)
-        evo = DeviceEvolution(pop, seed=11, pack_by_lifetime=pack)
-        per_gen, cost = [], []
+        evo = DeviceEvolution(pop, seed=11, place=place)
+        per_gen = []
         for g in range(gens):
             best, gbest, rec = evo.step(T)
             rows = rec[:, :3].cpu().numpy()
             per_gen.append(rows[np.lexsort(rows.T[::-1])])
-            life = rec[:, 1].cpu().numpy().reshape(-1, 8)
-            cost.append(int(life.max(axis=1).sum()) * 8)
             if g > 0 and evo.elite is not None:
                 assert torch.equal(pop.local.genome_of(0), evo.elite)     # the elite sits in slot 0 of the new generation
-        runs[pack] = (list(evo.history), per_gen, cost)
-    assert runs[False][0] == runs[True][0]
-    for a, b in zip(runs[False][1], runs[True][1]):
-        assert np.array_equal(a, b)
-    # generation 0 is placed as given; from generation 1 on the sorted placement does less masked work
-    plain, packed = sum(runs[False][2][1:]), sum(runs[True][2][1:])
-    assert packed < 0.97 * plain, (plain, packed)            # measured: -8 % (a child's lifetime barely follows its parent's)
+            if place == "parent":
+                first = pop.local.last_parents.long()[pop.local.last_order.long()][1:]
+                assert bool((first[1:] >= first[:-1]).all())              # neighbours in the gather
+        runs[place] = (list(evo.history), per_gen)
+    for place in ("parent", "lifetime"):
+        assert runs[None][0] == runs[place][0]
+        for a, b in zip(runs[None][1], runs[place][1]):
+            assert np.array_equal(a, b)
+    assert len({h for h in runs[None][0]}) > 1                            # the run does evolve
 
 
 @pytest.mark.parametrize("hidden,n,T", [((32, 32), 3000, 1500), ((16, 16), 1030, 2000), ((64, 64, 64), 300, 700), ((10, 10), 9, 300)])
-def test_compacting_rollout_is_bit_identical(Population, torch, hidden, n, T):
-    """Population.fly(engine="resident", compact=True) re-packs the drones still flying between segments
-    of the episode; every drone still executes its own timesteps with its own genome, so final states,
-    integer bookkeeping and records equal the plain rollout bit for bit -- on a population where most
-    drones crash at scattered times, a few fly the whole episode, and some crash into a wall."""
+def test_work_queue_rollout_is_bit_identical(Population, torch, hidden, n, T):
+    """The resident kernel hands drones to lane groups from a work queue (a group whose drone has crashed
+    takes the next one), so groups of one wavefront are at different timesteps of different drones.  Every
+    drone still executes its own timesteps with its own genome: final states, integer bookkeeping and
+    records equal the step engine bit for bit -- on a population where most drones crash at scattered
+    times, a few fly the whole episode, some hit a wall, and there are more drones than the persistent grid
+    has groups only at the largest size; an episode continued in two parts equals the whole."""
     from test_gpu_parity import _mixed_genomes
     spec, genes, cls = _mixed_genomes(hidden, n, seed=n)
     rng = np.random.default_rng(1)
@@ -363,17 +365,23 @@ def test_compacting_rollout_is_bit_identical(Population, torch, hidden, n, T):
     genes = genes.astype(np.float32).astype(np.float64)
     walls = np.array([[3.0, 3.0, 8.0, 4.5, 7.0, 12.0]])
     out = []
-    for kw in (dict(engine="step"), dict(engine="resident"), dict(engine="resident", compact=True)):
+    for engine in ("step", "resident"):
         pop = Population(n, hidden, walls=walls)
         pop.set_genomes(genes)
-        pop.fly(T, **kw)
+        pop.fly(T, engine=engine)
         out.append((pop.fstate.clone(), pop.istate.clone(), pop.records.clone()))
-    for other in out[1:]:
-        for a, b in zip(out[0], other):
-            assert torch.equal(a, b)
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
     life = (out[0][1][2] >> 1).cpu().numpy()
     assert (life < T).mean() > 0.3 and (life == T).any()
-    # a population that is dead from the start, and one in which nobody dies, take the same path
-    pop = Population(64, hidden)
-    pop.fly(50, engine="resident", compact=True)                           # zero genomes: everyone climbs, nobody crashes
-    assert not pop.results()["crashed"].any()
+    import ctypes as C
+    from learning_drones_amd import _native
+    pop = Population(n, hidden, walls=walls)                               # the same episode in two resident launches
+    pop.set_genomes(genes)
+    for k in (T // 3, T - T // 3):
+        _native.check(_native.lib().ld_fly_steps_resident_f32(C.byref(pop.sim), C.byref(pop.episode), C.byref(pop.spec),
+                                                              pop._ptr(pop.coins_dev), pop._ptr(pop.walls_dev), pop._ptr(pop.genomes),
+                                                              pop._ptr(pop.fstate), pop._ptr(pop.istate), n, k, pop._ptr(pop.queue),
+                                                              pop._stream()), "ld_fly_steps_resident_f32")
+    pop.finalize()
+    assert torch.equal(pop.records, out[0][2]) and torch.equal(pop.fstate, out[0][0])

@@ -190,8 +190,9 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ld_debug_force_generic(1) == 0 and lib.ld_debug_force_generic(0) == 1
     res = lib.ld_fly_rollout_resident_f32
     unsupported = MlpSpec.from_hidden((12,))                 # no unrolled / resident specialisation
-    assert res(C.byref(sim), C.byref(ep), C.byref(unsupported), fake, None, fake, fake, fake, fake, 8, 10, None) == SPEC
-    assert res(C.byref(sim), C.byref(ep), C.byref(spec), None, None, None, None, None, None, 0, 10, None) == OK
+    assert res(C.byref(sim), C.byref(ep), C.byref(unsupported), fake, None, fake, fake, fake, fake, 8, 10, fake, None) == SPEC
+    assert res(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, fake, 8, 10, None, None) == NULL     # no queue word
+    assert res(C.byref(sim), C.byref(ep), C.byref(spec), None, None, None, None, None, None, 0, 10, None, None) == OK
     assert lib.ld_genome_words(C.byref(spec), 65) == 2 * 64 * 149 and lib.ld_genome_words(C.byref(spec), 0) == 0
     assert lib.ld_genome_words(C.byref(spec), -1) == SIZE
     for code in (0, -1, -2, -3, -4, -5, -6, -99):

@@ -81,14 +81,11 @@ template <typename Real> inline EpT<Real> make_ep(const ld_episode_params& e)
 //   a_lin = (Rz Ry Rx)[:,2] * sum(T)/m - [0,0,G/m] + wind * c_w/m
 //   a_rot = Tr(roll, pitch) * (([L,M,N] + M_p) * 1/I)
 // ---------------------------------------------------------------------------------------------
+// sc = sin / cos of roll, pitch, yaw: sr, cr, sp, cp, sy, cy
 template <typename Real, typename Sim>
-__device__ __forceinline__ void accel_closed(const Sim& p, const Real ang[3], const Real u[4],
-                                             Real lin[3], Real rot[3])
+__device__ __forceinline__ void accel_closed_sc(const Sim& p, const Real sc[6], const Real u[4], Real lin[3], Real rot[3])
 {
-    Real sr, cr, sp, cp, sy, cy;
-    Math<Real>::sincos(ang[0], &sr, &cr);
-    Math<Real>::sincos(ang[1], &sp, &cp);
-    Math<Real>::sincos(ang[2], &sy, &cy);
+    const Real sr = sc[0], cr = sc[1], sp = sc[2], cp = sc[3], sy = sc[4], cy = sc[5];
     const Real cf = (Real)p.coef_force, cm = (Real)p.coef_moment, r = (Real)p.radius_motor;
     const Real inv_m = (Real)1 / (Real)p.mass_total;
     const Real T0 = u[0] * cf, T1 = u[1] * cf, T2 = u[2] * cf, T3 = u[3] * cf;
@@ -109,6 +106,17 @@ __device__ __forceinline__ void accel_closed(const Sim& p, const Real ang[3], co
     rot[0] = b0 + (sr * tp) * b1 + (cr * tp) * b2;
     rot[1] = cr * b1 - sr * b2;
     rot[2] = (sr * b1 + cr * b2) * inv_cp;
+}
+
+template <typename Real, typename Sim>
+__device__ __forceinline__ void accel_closed(const Sim& p, const Real ang[3], const Real u[4],
+                                             Real lin[3], Real rot[3])
+{
+    Real sc[6];
+    Math<Real>::sincos(ang[0], &sc[0], &sc[1]);
+    Math<Real>::sincos(ang[1], &sc[2], &sc[3]);
+    Math<Real>::sincos(ang[2], &sc[4], &sc[5]);
+    accel_closed_sc<Real, Sim>(p, sc, u, lin, rot);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -215,13 +223,21 @@ template <typename Real> struct DroneRegs {
 
 // drone/drone.py:129-165 (+ build-defined wall boxes held in LDS).  Returns true if crashed;
 // `reward` receives the crash / instability terms.
+// `sc` (closed form only): sin / cos of the three angles computed elsewhere -- the resident kernel computes
+// them on three different lanes of the drone's group at once instead of three times on every lane.
 template <typename Real, bool Faithful, typename Sim, typename Ep>
 __device__ __forceinline__ bool measure(const Sim& sim, const Ep& ep,
-                                        const Real* __restrict__ lds_walls, DroneRegs<Real>& d, int32_t& reward)
+                                        const Real* __restrict__ lds_walls, DroneRegs<Real>& d, int32_t& reward,
+                                        const Real* sc = nullptr)
 {
     Real lin[3], rot[3];
     const Real dt = (Real)sim.dt;
-    accelerations<Real, Faithful>(sim, &d.s[6], d.u, lin, rot);
+    if constexpr (!Faithful) {
+        if (sc) accel_closed_sc<Real, Sim>(sim, sc, d.u, lin, rot);
+        else accel_closed<Real, Sim>(sim, &d.s[6], d.u, lin, rot);
+    } else {
+        accelerations<Real, Faithful>(sim, &d.s[6], d.u, lin, rot);
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) verlet<Real>(d.s[i], d.s[3 + i], d.acc[i], lin[i], dt);
 #pragma unroll

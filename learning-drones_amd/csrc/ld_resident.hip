@@ -1,18 +1,51 @@
 // ld_resident.hip — instantiations of the genome-resident rollout (ld_resident.hpp).
 #include "ld_resident.hpp"
 
-// (lanes per drone, hidden widths...): the lane count trades gene registers per lane against drones
-// per wavefront.  Gene registers per lane: 10-10 65, 16-16 83, 32-32 229 (L = 8; measured 1.5x faster
-// than L = 16 with 131: eight drones share each wavefront's redundant physics and every lane has four
-// independent fma chains), 64-64-64 211 (one wavefront per drone).
-#ifndef LD_RES_A
-#define LD_RES_A 8
-#define LD_RES_B 8
-#define LD_RES_C 8
+// (lanes per drone, hidden widths...).  More lanes per drone mean fewer gene registers per lane (more
+// wavefronts per SIMD to hide the latency of the step's dependent chain: sincosf -> accelerations ->
+// integrator -> three layers with an LDS exchange each) but fewer drones per wavefront sharing the
+// per-step work that every lane repeats (the rigid-body step).  Measured per spec (scripts/time_resident.py,
+// profiles/r02_resident_lanes.json); the defaults below are the fastest of each row.
+#ifndef LD_RES_8_10
+#define LD_RES_8_10 2
 #endif
-#define LD_FOR_EACH_RESIDENT(X)                                                                          \
-    X(8, 8, 10) X(LD_RES_A, 10, 10) X(LD_RES_B, 16, 16) X(LD_RES_C, 32, 32) X(64, 64, 64, 64)               \
-    X(4, 16) X(4, 32) X(8, 64) X(4, 8, 8) X(8, 24, 24) X(16, 48, 48) X(32, 64, 64) X(16, 32, 32, 32)
+#ifndef LD_RES_10_10
+#define LD_RES_10_10 2
+#endif
+#ifndef LD_RES_16_16
+#define LD_RES_16_16 4
+#endif
+#ifndef LD_RES_32_32
+#define LD_RES_32_32 16
+#endif
+#ifndef LD_RES_16
+#define LD_RES_16 2
+#endif
+#ifndef LD_RES_32
+#define LD_RES_32 2
+#endif
+#ifndef LD_RES_64
+#define LD_RES_64 4
+#endif
+#ifndef LD_RES_8_8
+#define LD_RES_8_8 2
+#endif
+#ifndef LD_RES_24_24
+#define LD_RES_24_24 8
+#endif
+#ifndef LD_RES_48_48
+#define LD_RES_48_48 16
+#endif
+#ifndef LD_RES_64_64
+#define LD_RES_64_64 32
+#endif
+#ifndef LD_RES_32_32_32
+#define LD_RES_32_32_32 32
+#endif
+#define LD_FOR_EACH_RESIDENT(X)                                                                              \
+    X(LD_RES_8_10, 8, 10) X(LD_RES_10_10, 10, 10) X(LD_RES_16_16, 16, 16) X(LD_RES_32_32, 32, 32) X(64, 64, 64, 64)   \
+    X(LD_RES_16, 16) X(LD_RES_32, 32) X(LD_RES_64, 64) X(LD_RES_8_8, 8, 8) X(LD_RES_24_24, 24, 24)                  \
+    X(LD_RES_48_48, 48, 48) X(LD_RES_64_64, 64, 64) X(LD_RES_32_32_32, 32, 32, 32)
 
 template <int L, int... H> static bool resident_matches(const ld_mlp_spec& s) { return ld::NetShape<H...>::matches(s); }
 

@@ -124,7 +124,25 @@ fly_resident_kernel(const SimT<float> sim, const EpT<float> ep, const double* __
             if (coin_distance<float>(c, d.s) < c[3]) { r += (int32_t)c[4]; nc += 1; }
         }
         DroneRegs<float> e = d;
-        const bool crashed = measure<float, false>(sim, ep, tab.walls, e, r);
+        // sin / cos of roll, pitch, yaw: lanes 0, 1, 2 of the group take one angle each (the other lanes
+        // compute a throw-away copy of yaw's) and the six values are read back from those lanes --
+        // one sincosf per step instead of three on every lane of the group.  Same function, same inputs:
+        // bit-identical to the step kernels.
+        float sc[6];
+        if constexpr (L >= 4) {
+            const float angle = l == 0 ? d.s[6] : (l == 1 ? d.s[7] : d.s[8]);
+            float sn, cs;
+            Math<float>::sincos(angle, &sn, &cs);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                sc[2 * a] = __shfl(sn, g * L + a);
+                sc[2 * a + 1] = __shfl(cs, g * L + a);
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) Math<float>::sincos(d.s[6 + a], &sc[2 * a], &sc[2 * a + 1]);
+        }
+        const bool crashed = measure<float, false>(sim, ep, tab.walls, e, r, sc);
         current_coin<float>(ep, tab.coins, nc, c);
 
         // ---- controller (evolve/brain.py:41-54): lane l owns neurons l, l+L, ... of every layer

@@ -300,6 +300,15 @@ int ld_fly_rollout_resident_f32(const ld_sim_params *sim, const ld_episode_param
                                 int32_t *istate, ld_fitness_record *records, int64_t n, int32_t timesteps,
                                 int32_t *queue, void *stream);
 
+/* The same engine in the float64 reference-tracking arithmetic (the reference's rounding points included;
+ * bit-identical to ld_fly_rollout_f64), so that one drone, or a small population, takes ONE launch per
+ * episode instead of one per timestep.  A gene takes two registers: available for 8-10, 10-10, 16-16,
+ * 32-32, 16, 32, 64, 8-8, 24-24; LD_ERR_SPEC for the other specs (ld_fly_rollout_f64 runs every spec). */
+int ld_fly_rollout_resident_f64(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
+                                const double *coins, const double *walls, const double *genomes, double *fstate,
+                                int32_t *istate, ld_fitness_record *records, double *distance_f64, int64_t n,
+                                int32_t timesteps, int32_t *queue, void *stream);
+
 /* `n_steps` loop iterations of the genome-resident kernel WITHOUT the finalize launch (the episode can be
  * continued; finish with ld_fly_finalize_f32).  `queue` as in ld_fly_rollout_resident_f32. */
 int ld_fly_steps_resident_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,

@@ -27,6 +27,7 @@ EXPORTS = (
     "ld_ga_select", "ld_ga_breed_f32", "ld_ga_breed_f64", "ld_pid_episode_f32", "ld_pid_episode_f64",
     "ld_fly_rollout_resident_f32", "ld_debug_force_generic", "ld_accelerations_f32", "ld_accelerations_f64",
     "ld_fly_steps_f32", "ld_fly_rollout_steps_f32", "ld_fly_rollout_geometry_f32", "ld_fly_steps_resident_f32",
+    "ld_fly_rollout_resident_f64",
 )
 ABI_VERSION = 2
 
@@ -93,6 +94,7 @@ def _declare(h: C.CDLL) -> None:
     h.ld_fly_rollout_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, i64, i32, vp]
     h.ld_fly_rollout_f64.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]
     h.ld_fly_rollout_resident_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]
+    h.ld_fly_rollout_resident_f64.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]
     h.ld_fly_steps_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, i64, i32, i32, vp]
     h.ld_fly_rollout_steps_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
     h.ld_accelerations_f32.argtypes = [sim, vp, vp, vp, vp, i64, vp]

@@ -14,6 +14,8 @@
 
 int ld_resident_dispatch(const ld_sim_params*, const ld_episode_params*, const ld_mlp_spec*, const double*, const double*,
                          const float*, float*, int32_t*, int64_t, int32_t, int32_t*, hipStream_t);   // ld_resident.hip
+int ld_resident_dispatch_f64(const ld_sim_params*, const ld_episode_params*, const ld_mlp_spec*, const double*, const double*,
+                             const double*, double*, int32_t*, int64_t, int32_t, int32_t*, hipStream_t);
 
 using ld::blocks_for;
 using ld::check_launch;
@@ -351,6 +353,23 @@ int ld_fly_rollout_resident_f32(const ld_sim_params* sim, const ld_episode_param
     }
     if (rc) return rc;
     return finalize_impl<float>(ep, coins, fstate, istate, records, nullptr, n, stream);
+}
+
+int ld_fly_rollout_resident_f64(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,
+                                const double* coins, const double* walls, const double* genomes, double* fstate,
+                                int32_t* istate, ld_fitness_record* records, double* distance_f64, int64_t n,
+                                int32_t timesteps, int32_t* queue, void* stream)
+{
+    if (timesteps < 0) return LD_ERR_SIZE;
+    int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
+    if (rc || n == 0) return rc;
+    if (!queue) return LD_ERR_NULL;
+    if (timesteps > 0) {
+        rc = ld_resident_dispatch_f64(sim, ep, spec, coins, walls, genomes, fstate, istate, n, timesteps, queue,
+                                      static_cast<hipStream_t>(stream));
+        if (rc) return rc;
+    }
+    return finalize_impl<double>(ep, coins, fstate, istate, records, distance_f64, n, stream);
 }
 
 int ld_pid_episode_f32(const ld_sim_params* sim, const float* gains, const double* coins, int32_t n_coins,

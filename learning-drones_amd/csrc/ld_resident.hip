@@ -47,16 +47,34 @@
     X(LD_RES_16, 16) X(LD_RES_32, 32) X(LD_RES_64, 64) X(LD_RES_8_8, 8, 8) X(LD_RES_24_24, 24, 24)                  \
     X(LD_RES_48_48, 48, 48) X(LD_RES_64_64, 64, 64) X(LD_RES_32_32_32, 32, 32, 32)
 
-template <int L, int... H> static bool resident_matches(const ld_mlp_spec& s) { return ld::NetShape<H...>::matches(s); }
+template <int... H> static bool resident_matches(const ld_mlp_spec& s) { return ld::NetShape<H...>::matches(s); }
 
 int ld_resident_dispatch(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,
                          const double* coins, const double* walls, const float* genomes, float* fstate, int32_t* istate,
                          int64_t n, int32_t timesteps, int32_t* queue, hipStream_t stream)
 {
 #define X(L, ...)                                                                                      \
-    if (resident_matches<L, __VA_ARGS__>(*spec))                                                       \
-        return ld::launch_fly_resident<L, __VA_ARGS__>(sim, ep, coins, walls, genomes, fstate, istate, n, timesteps, queue, stream);
+    if (resident_matches<__VA_ARGS__>(*spec))                                                          \
+        return ld::launch_fly_resident<float, false, L, __VA_ARGS__>(sim, ep, coins, walls, genomes, fstate, istate, n, timesteps, queue, stream);
     LD_FOR_EACH_RESIDENT(X)
+#undef X
+    return LD_ERR_SPEC;
+}
+
+// float64 (the reference's arithmetic, rounding points included): a gene takes two registers, so a drone gets
+// more lanes, and the specs whose genome does not fit at 64 lanes per drone have no float64 resident kernel
+// (LD_ERR_SPEC: ld_fly_rollout_f64 runs every spec).
+#define LD_FOR_EACH_RESIDENT_F64(X)                                                                      \
+    X(8, 8, 10) X(8, 10, 10) X(16, 16, 16) X(64, 32, 32) X(8, 16) X(16, 32) X(32, 64) X(8, 8, 8) X(32, 24, 24)
+
+int ld_resident_dispatch_f64(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,
+                             const double* coins, const double* walls, const double* genomes, double* fstate, int32_t* istate,
+                             int64_t n, int32_t timesteps, int32_t* queue, hipStream_t stream)
+{
+#define X(L, ...)                                                                                      \
+    if (resident_matches<__VA_ARGS__>(*spec))                                                          \
+        return ld::launch_fly_resident<double, true, L, __VA_ARGS__>(sim, ep, coins, walls, genomes, fstate, istate, n, timesteps, queue, stream);
+    LD_FOR_EACH_RESIDENT_F64(X)
 #undef X
     return LD_ERR_SPEC;
 }

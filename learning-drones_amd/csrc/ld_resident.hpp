@@ -1,4 +1,5 @@
-// ld_resident.hpp — whole-episode rollout with the genome resident in registers.
+// ld_resident.hpp — whole-episode rollout with the genome resident in registers (float32 production
+// arithmetic, and the float64 reference-tracking arithmetic for the specs whose genome fits in doubles).
 //
 // The contract kernel (fly_step_kernel, one launch per timestep, one lane per drone) re-reads every
 // drone's 4P bytes of genes from HBM on every step: it is an HBM stream by construction and runs at
@@ -54,25 +55,26 @@ template <int L, int... H> struct ResidentLayout {
 // until the LAST of its 64 / L drones is done, and in a GA generation (most children crash within a few
 // hundred steps, a few fly the whole episode, scattered at random) that is ~2x the work of the live
 // drone-steps.  Every wavefront leaves its loop once the counter has passed n and its groups have drained.
-template <int L, int... H>
+template <typename Real, bool Faithful, int L, int... H>
 __global__ void __launch_bounds__(64, LD_RES_WAVES)
-fly_resident_kernel(const SimT<float> sim, const EpT<float> ep, const double* __restrict__ coins,
-                    const double* __restrict__ walls, const float* __restrict__ genomes, float* __restrict__ fstate,
+fly_resident_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restrict__ coins,
+                    const double* __restrict__ walls, const Real* __restrict__ genomes, Real* __restrict__ fstate,
                     int32_t* __restrict__ istate, const int64_t n, const int32_t timesteps, int32_t* __restrict__ queue)
 {
+    constexpr bool Fma = !Faithful;                       // float32: fma chain; float64: the reference's multiply, then add
     using Lay = ResidentLayout<L, H...>;
     using Shape = typename Lay::Shape;
     constexpr int G = Lay::kDrones;
     constexpr int MW = Shape::max_width();
-    __shared__ Tables<float> tab;
-    __shared__ float xch[2][G][MW + 4];                   // layer outputs, ping-pong, one padded row per drone
+    __shared__ Tables<Real> tab;
+    __shared__ Real xch[2][G][MW + 4];                   // layer outputs, ping-pong, one padded row per drone
 
     const int lane = threadIdx.x, g = lane / L, l = lane % L;
-    stage_tables<float>(tab, ep, coins, walls);
+    stage_tables<Real>(tab, ep, coins, walls);
     __syncthreads();
 
-    float genes[Lay::kGeneRegs];
-    DroneRegs<float> d;
+    Real genes[Lay::kGeneRegs];
+    DroneRegs<Real> d;
     int32_t reward = 0, ncoll = 0, flight_time = 0, t_left = 0;
     bool crashed_state = false;
     int64_t drone = (int64_t)blockIdx.x * G + g;          // first assignment; the queue hands out gridDim.x * G, ...
@@ -106,7 +108,7 @@ fly_resident_kernel(const SimT<float> sim, const EpT<float> ep, const double* __
                 const int32_t status = istate[(int64_t)LD_I_STATUS * n + drone];
                 reward = istate[(int64_t)LD_I_REWARD * n + drone];
                 ncoll = istate[(int64_t)LD_I_COINS * n + drone];
-                load_drone<float>(fstate, n, drone, d);
+                load_drone<Real>(fstate, n, drone, d);
                 crashed_state = (status & 1) != 0;
                 flight_time = status >> 1;
                 t_left = timesteps;
@@ -119,34 +121,33 @@ fly_resident_kernel(const SimT<float> sim, const EpT<float> ep, const double* __
         // ---- flight/__init__.py:41-52, :79 (identical to fly_step_kernel)
         int32_t r = reward + ep.reward_time;
         int32_t nc = ncoll;
-        float c[LD_COIN_STRIDE];
-        if (current_coin<float>(ep, tab.coins, nc, c)) {
-            if (coin_distance<float>(c, d.s) < c[3]) { r += (int32_t)c[4]; nc += 1; }
+        Real c[LD_COIN_STRIDE];
+        if (current_coin<Real>(ep, tab.coins, nc, c)) {
+            if (coin_distance<Real>(c, d.s) < c[3]) { r += (int32_t)c[4]; nc += 1; }
         }
-        DroneRegs<float> e = d;
+        DroneRegs<Real> e = d;
         // sin / cos of roll, pitch, yaw: lanes 0, 1, 2 of the group take one angle each (the other lanes
         // compute a throw-away copy of yaw's) and the six values are read back from those lanes --
         // one sincosf per step instead of three on every lane of the group.  Same function, same inputs:
         // bit-identical to the step kernels.
-        float sc[6];
-        if constexpr (L >= 4) {
-            const float angle = l == 0 ? d.s[6] : (l == 1 ? d.s[7] : d.s[8]);
-            float sn, cs;
-            Math<float>::sincos(angle, &sn, &cs);
+        bool crashed;
+        if constexpr (!Faithful && L >= 4) {
+            const Real angle = l == 0 ? d.s[6] : (l == 1 ? d.s[7] : d.s[8]);
+            Real sn, cs, sc[6];
+            Math<Real>::sincos(angle, &sn, &cs);
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 sc[2 * a] = __shfl(sn, g * L + a);
                 sc[2 * a + 1] = __shfl(cs, g * L + a);
             }
+            crashed = measure<Real, Faithful>(sim, ep, tab.walls, e, r, sc);
         } else {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) Math<float>::sincos(d.s[6 + a], &sc[2 * a], &sc[2 * a + 1]);
+            crashed = measure<Real, Faithful>(sim, ep, tab.walls, e, r);
         }
-        const bool crashed = measure<float, false>(sim, ep, tab.walls, e, r, sc);
-        current_coin<float>(ep, tab.coins, nc, c);
+        current_coin<Real>(ep, tab.coins, nc, c);
 
         // ---- controller (evolve/brain.py:41-54): lane l owns neurons l, l+L, ... of every layer
-        float act[MW];
+        Real act[MW];
 #pragma unroll
         for (int k = 0; k < 12; ++k) act[k] = e.s[k];
 #pragma unroll
@@ -159,22 +160,22 @@ fly_resident_kernel(const SimT<float> sim, const EpT<float> ep, const double* __
             // (each neuron's own sum still runs in gene order, so the result is unchanged)
             constexpr int Q = Lay::slots(layer);
             constexpr int stride = n_in + 1;
-            float acc[Q];
+            Real acc[Q];
             static_for<0, Q>([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value;
-                acc[q] = mac<float, true>(genes[Lay::reg_offset(layer) + q * stride], act[0], 0.0f);
+                acc[q] = mac<Real, Fma>(genes[Lay::reg_offset(layer) + q * stride], act[0], (Real)0);
             });
             static_for<1, n_in>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;
                 static_for<0, Q>([&](auto qc) __attribute__((always_inline)) {
                     constexpr int q = decltype(qc)::value;
-                    acc[q] = mac<float, true>(genes[Lay::reg_offset(layer) + q * stride + k], act[k], acc[q]);
+                    acc[q] = mac<Real, Fma>(genes[Lay::reg_offset(layer) + q * stride + k], act[k], acc[q]);
                 });
             });
             static_for<0, Q>([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value;
-                const float sum = acc[q] + genes[Lay::reg_offset(layer) + q * stride + n_in];
-                const float y = last ? sigmoid04<float>(sum) : relu<float>(sum);
+                const Real sum = acc[q] + genes[Lay::reg_offset(layer) + q * stride + n_in];
+                const Real y = last ? sigmoid04<Real>(sum) : relu<Real>(sum);
                 const int j = l + q * L;
                 if (j < n_out) xch[layer & 1][g][j] = y;
             });
@@ -206,7 +207,7 @@ fly_resident_kernel(const SimT<float> sim, const EpT<float> ep, const double* __
         if (__any(done)) {
             int32_t next = 0;
             if (done && l == 0) {
-                store_drone<float>(fstate, n, drone, d);
+                store_drone<Real>(fstate, n, drone, d);
                 istate[(int64_t)LD_I_REWARD * n + drone] = reward;
                 istate[(int64_t)LD_I_COINS * n + drone] = ncoll;
                 istate[(int64_t)LD_I_STATUS * n + drone] = 2 * flight_time + (crashed_state ? 1 : 0);
@@ -223,9 +224,9 @@ fly_resident_kernel(const SimT<float> sim, const EpT<float> ep, const double* __
     }
 }
 
-template <int L, int... H>
+template <typename Real, bool Faithful, int L, int... H>
 int launch_fly_resident(const ld_sim_params* sim, const ld_episode_params* ep, const double* coins, const double* walls,
-                        const float* genomes, float* fstate, int32_t* istate, int64_t n, int32_t timesteps, int32_t* queue,
+                        const Real* genomes, Real* fstate, int32_t* istate, int64_t n, int32_t timesteps, int32_t* queue,
                         hipStream_t stream)
 {
     constexpr int G = 64 / L;
@@ -233,7 +234,8 @@ int launch_fly_resident(const ld_sim_params* sim, const ld_episode_params* ep, c
     static int resident_blocks = 0;
     if (resident_blocks == 0) {
         int per_cu = 0, dev = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fly_resident_kernel<L, H...>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fly_resident_kernel<Real, Faithful, L, H...>, 64, 0) != hipSuccess || per_cu < 1)
+            per_cu = 4;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
             cus = 256;
         resident_blocks = per_cu * cus;
@@ -241,8 +243,8 @@ int launch_fly_resident(const ld_sim_params* sim, const ld_episode_params* ep, c
     const unsigned blocks = (unsigned)std::min<int64_t>(blocks_for(n, G), resident_blocks);
     hipError_t e = hipMemsetAsync(queue, 0, sizeof(int32_t), stream);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(queue)");
-    hipLaunchKernelGGL((fly_resident_kernel<L, H...>), dim3(blocks), dim3(64), 0, stream, make_sim<float>(*sim),
-                       make_ep<float>(*ep), coins, walls, genomes, fstate, istate, n, timesteps, queue);
+    hipLaunchKernelGGL((fly_resident_kernel<Real, Faithful, L, H...>), dim3(blocks), dim3(64), 0, stream, make_sim<Real>(*sim),
+                       make_ep<Real>(*ep), coins, walls, genomes, fstate, istate, n, timesteps, queue);
     return check_launch("fly_resident_kernel");
 }
 

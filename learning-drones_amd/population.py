@@ -233,6 +233,12 @@ class Population:
     # layer specs with an unrolled step kernel and a resident engine (csrc/ld_kernels.hpp, ld_resident.hip)
     RESIDENT_SPECS = ((8, 10), (10, 10), (16, 16), (32, 32), (64, 64, 64), (16,), (32,), (64,), (8, 8), (24, 24),
                       (48, 48), (64, 64), (32, 32, 32))
+    # ... and the subset whose genome fits in registers as doubles (ld_fly_rollout_resident_f64)
+    RESIDENT_SPECS_F64 = ((8, 10), (10, 10), (16, 16), (32, 32), (16,), (32,), (64,), (8, 8), (24, 24))
+
+    def has_resident_engine(self) -> bool:
+        specs = self.RESIDENT_SPECS if self.precision == "f32" else self.RESIDENT_SPECS_F64
+        return self.spec.hidden_widths in specs
 
     def fly(self, timesteps: int = 2500, engine: str = "step", steps_per_launch: Optional[int] = None,
             waves_per_block: int = 0):
@@ -244,7 +250,7 @@ class Population:
         state in registers in between, and a genome block's 64 drones get as many wavefronts as fill the
         chip; steps_per_launch / waves_per_block make that geometry explicit (ld_fly_rollout_steps_f32;
         steps_per_launch=1 is one launch per timestep).  Results do not depend on the geometry.
-        engine="resident" (float32, specs RESIDENT_SPECS): one launch for the whole episode with the genome
+        engine="resident" (specs RESIDENT_SPECS in float32, RESIDENT_SPECS_F64 in float64): one launch for the whole episode with the genome
         held in registers and drones handed to lane groups from a work queue (ld_fly_rollout_resident_f32);
         bit-identical results, 3-6x faster, and a population in which most drones crash early costs about
         its live drone-steps.
@@ -255,12 +261,15 @@ class Population:
                 self._ptr(self.walls_dev), self._ptr(self.genomes), self._ptr(self.fstate), self._ptr(self.istate),
                 self._ptr(self.records)]
         if engine == "auto":
-            engine = "resident" if (self.precision == "f32" and self.spec.hidden_widths in self.RESIDENT_SPECS) else "step"
+            engine = "resident" if self.has_resident_engine() else "step"
         if engine == "resident":
-            if self.precision != "f32" or self.spec.hidden_widths not in self.RESIDENT_SPECS:
-                raise ValueError("the resident engine is float32 and covers the specs " + str(self.RESIDENT_SPECS))
+            if not self.has_resident_engine():
+                raise ValueError(f"no resident engine for spec {self.spec.hidden_widths} in {self.precision}: float32 covers "
+                                 f"{self.RESIDENT_SPECS}, float64 {self.RESIDENT_SPECS_F64}")
+            if self.precision == "f64":
+                args.append(self._ptr(self.distance))
             args += [self.n, int(timesteps), self._ptr(self.queue), self._stream()]
-            _native.check(_native.lib().ld_fly_rollout_resident_f32(*args), "ld_fly_rollout_resident_f32")
+            _native.check(self._fn("ld_fly_rollout_resident")(*args), "ld_fly_rollout_resident")
             self._finalized = True
             return self.records
         if engine != "step":

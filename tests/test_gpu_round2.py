@@ -10,6 +10,7 @@ import pytest
 
 from conftest import REPO
 from learning_drones_amd.params import EpisodeParams, MlpSpec, SimParams, coin_chain_reference
+from test_gpu_parity import CHAOTIC
 
 pytestmark = pytest.mark.gpu
 RTOL_F32 = 1e-4                                  # BASELINE.json north_star: "matching CPU reference trajectories to rtol=1e-4"
@@ -385,3 +386,52 @@ def test_work_queue_rollout_is_bit_identical(Population, torch, hidden, n, T):
                                                               pop._stream()), "ld_fly_steps_resident_f32")
     pop.finalize()
     assert torch.equal(pop.records, out[0][2]) and torch.equal(pop.fstate, out[0][0])
+
+
+# ------------------------------------------------------------------------------------------- float64 resident engine
+@pytest.mark.parametrize("hidden,n,T", [((10, 10), 130, 900), ((16, 16), 200, 700), ((32, 32), 70, 500), ((8, 10), 65, 400), ((16,), 40, 300),
+                                        ((32,), 40, 300), ((64,), 40, 300), ((8, 8), 40, 300), ((24, 24), 40, 300)])
+def test_resident_engine_f64_is_bit_identical(Population, torch, hidden, n, T):
+    """ld_fly_rollout_resident_f64 (one launch per episode, the reference's arithmetic with its float32
+    rounding points) against one launch per timestep of the float64 step kernels: bit for bit, distances
+    included."""
+    from test_gpu_parity import _mixed_genomes
+    spec, genes, cls = _mixed_genomes(hidden, n, seed=3 * n)
+    out = []
+    for engine in ("step", "resident"):
+        pop = Population(n, hidden, precision="f64", walls=np.array([[3.0, 3.0, 8.0, 4.5, 7.0, 12.0]]))
+        pop.set_genomes(genes)
+        pop.fly(T, engine=engine)
+        out.append((pop.fstate.clone(), pop.istate.clone(), pop.records.clone(), pop.distance.clone()))
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
+    crashed = (out[0][1][2] & 1).bool()
+    assert crashed.any() and not crashed.all()
+    with pytest.raises(ValueError):
+        Population(4, (64, 64, 64), precision="f64").fly(10, engine="resident")   # does not fit in registers as doubles
+
+
+def test_closed_loop_f64_resident_tracks_reference(Population, g3):
+    """The reference's own closed-loop episodes (golden G3) through the float64 RESIDENT engine -- what the scalar
+    Drone / fly() drop-in now runs (engine="auto"), one launch per episode: every integer outcome exact, the final
+    distance to 1e-8, for every episode whose spec has a float64 resident kernel."""
+    seen = 0
+    for ei in range(int(g3["n_episodes"])):
+        hidden = tuple(int(h) for h in g3[f"hidden_{ei}"])
+        if hidden not in Population.RESIDENT_SPECS_F64:
+            continue
+        pop = Population(1, hidden, precision="f64")
+        pop.set_genomes(g3[f"weights_{ei}"][None])
+        pop.fly(int(g3[f"timesteps_{ei}"]), engine="resident")
+        r, fin = pop.results()[0], g3[f"final_{ei}"]
+        assert (int(r["reward"]), int(r["coins"]), int(r["flight_time"]), bool(r["crashed"])) == \
+               (int(fin[0]), int(fin[2]), int(fin[3]), bool(fin[4])), ei
+        if ei in CHAOTIC:                                # grazes the cos(pitch) = 0 pole: integers + a loose distance, as in L0 / L3
+            assert abs(r["distance_to_coin"] - fin[5]) < 0.05, ei
+        else:
+            assert abs(r["distance_to_coin"] - fin[5]) <= 1e-8 * max(1.0, abs(fin[5])), ei
+            ref = g3[f"state_{ei}"][-1]
+            got = pop.state_numpy()[0, :12]
+            assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)) < 1e-8, ei
+        seen += 1
+    assert seen >= 40

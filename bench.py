@@ -109,6 +109,8 @@ def main():
                     "population, split over the ranks (BASELINE's 8-GPU target is quoted for a 65 536-drone population in all)")
     ap.add_argument("--steps-per-launch", type=int, default=0, help="timesteps per fused launch (0 = the library's choice)")
     ap.add_argument("--waves-per-block", type=int, default=0, help="wavefronts per 64-drone genome block (0 = the library's choice)")
+    ap.add_argument("--specialise", action="store_true", help="compile the unrolled kernels for --hidden at first use if the "
+                    "library does not ship them (learning_drones_amd.specialise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline rollout and its roofline (for rocprofv3 "
                     "runs: keeps every fused launch in the trace a full, live-population launch of the headline geometry)")
@@ -166,7 +168,7 @@ def main():
         sides, wall time = max over ranks; the fused launches' average duration from HIP events on the
         launch stream over the same region."""
         pop = ShardedPopulation(n_local * world, hidden, coins=coin_chain_reference(args.coins), precision="f32",
-                                device=device, process_group=dist.group.WORLD if dist else None)
+                                device=device, process_group=dist.group.WORLD if dist else None, specialise=args.specialise)
         assert pop.local.n == n_local
         pop.local.set_genomes(make_genomes(torch, n_local, hidden, device, seed=rank))
         geo = pop.local.rollout_geometry(T)
@@ -196,7 +198,9 @@ def main():
         bytes_per_launch = pop.local.bytes_per_launch(geo["steps_per_launch"])
         achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "kernel": "fly_split_kernel<float, L=%d, %s>" % (geo["waves_per_block"], "-".join(map(str, hidden))),
+                "kernel": ("fly_split_kernel<float, L=%d, %s>" % (geo["waves_per_block"], "-".join(map(str, hidden)))
+                           if geo["steps_per_launch"] > 1 or geo["waves_per_block"] > 1 or hidden in pop.local.RESIDENT_SPECS
+                           else "fly_step_kernel<float, GenericNet> (run-time layer spec)"),
                 "bytes_per_launch": bytes_per_launch, "launch_us": launch_ms * 1e3,
                 "timesteps_per_launch": geo["steps_per_launch"], "wavefronts_per_block": geo["waves_per_block"],
                 "launches_per_episode": geo["launches"],

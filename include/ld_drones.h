@@ -316,6 +316,30 @@ int ld_fly_steps_resident_f32(const ld_sim_params *sim, const ld_episode_params 
                               int32_t *istate, int64_t n, int32_t n_steps, int32_t *queue, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Specialisation of further layer specs at run time.  The library ships unrolled kernels for thirteen
+ * layer specs; every other spec runs the run-time-spec ("generic") kernels, which reach 47-68 % of the
+ * HBM roofline where the unrolled ones reach 85-90 %.  A host program that has hipcc can compile the
+ * unrolled kernels for one more spec (learning_drones_amd.build.build_specialisation writes a ten-line
+ * translation unit that instantiates csrc/ld_split.inc and csrc/ld_unrolled.inc for the spec, builds it
+ * into its own shared object and loads it) and register its two entry points here; from then on
+ * ld_fly_step_f32 / ld_fly_steps_f32 / ld_fly_rollout_f32 / ld_fly_rollout_steps_f32 / ld_mlp_forward_f32
+ * dispatch that spec to them (same arithmetic: results are bit-identical to the generic kernels).
+ * The registry is process-wide (at most 64 specs, guarded by a mutex); the generic kernels stay the
+ * fallback for everything that is not registered.  Returns LD_ERR_SIZE when the registry is full or the
+ * spec already has an unrolled kernel.
+ * ------------------------------------------------------------------------------------------- */
+typedef int (*ld_fly_steps_f32_fn)(const ld_sim_params *sim, const ld_episode_params *ep, const double *coins,
+                                   const double *walls, const float *genomes, float *fstate, int32_t *istate,
+                                   int64_t n, int32_t n_steps, int32_t waves_per_block, void *stream);
+typedef int (*ld_mlp_forward_f32_fn)(const ld_mlp_spec *spec, const float *genomes, const float *inputs,
+                                     float *outputs, int64_t n, void *stream);
+int ld_register_specialisation_f32(const ld_mlp_spec *spec, ld_fly_steps_f32_fn fly_steps,
+                                   ld_mlp_forward_f32_fn mlp_forward);
+/* 1 if ld_fly_step_f32 takes an unrolled kernel for this spec (built in or registered), 0 if the generic
+ * kernel, negative ld_status for an invalid spec. */
+int ld_has_specialisation_f32(const ld_mlp_spec *spec);
+
+/* ---------------------------------------------------------------------------------------------
  * Generation step on the device: the GA operators of evolve/util.py:5-78 and
  * Drone.mutate (drone/drone.py:167-172) applied to the device genome layout.  Random numbers come
  * from Philox4x32-10 keyed by (seed, generation, slot), so the result is a pure function of its

@@ -26,6 +26,9 @@ def __getattr__(name):
     if name in ("Drone",):
         from .drone.drone import Drone
         return Drone
+    if name == "specialise":
+        from ._native import specialise
+        return specialise
     if name in ("fly", "fly_population"):
         from . import flight
         return getattr(flight, name)

@@ -27,7 +27,7 @@ EXPORTS = (
     "ld_ga_select", "ld_ga_breed_f32", "ld_ga_breed_f64", "ld_pid_episode_f32", "ld_pid_episode_f64",
     "ld_fly_rollout_resident_f32", "ld_debug_force_generic", "ld_accelerations_f32", "ld_accelerations_f64",
     "ld_fly_steps_f32", "ld_fly_rollout_steps_f32", "ld_fly_rollout_geometry_f32", "ld_fly_steps_resident_f32",
-    "ld_fly_rollout_resident_f64",
+    "ld_fly_rollout_resident_f64", "ld_register_specialisation_f32", "ld_has_specialisation_f32",
 )
 ABI_VERSION = 2
 
@@ -100,6 +100,8 @@ def _declare(h: C.CDLL) -> None:
     h.ld_accelerations_f32.argtypes = [sim, vp, vp, vp, vp, i64, vp]
     h.ld_accelerations_f64.argtypes = [sim, vp, vp, vp, vp, i64, vp]
     h.ld_debug_force_generic.argtypes = [C.c_int]
+    h.ld_register_specialisation_f32.argtypes = [spec, vp, vp]
+    h.ld_has_specialisation_f32.argtypes = [spec]
     h.ld_fly_steps_resident_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, i64, i32, vp, vp]
     pi32 = C.POINTER(C.c_int32)
     h.ld_fly_rollout_geometry_f32.argtypes = [spec, i64, i32, pi32, pi32, pi32]
@@ -113,6 +115,29 @@ def _declare(h: C.CDLL) -> None:
         if name not in ("ld_strerror", "ld_last_hip_error", "ld_mlp_param_count", "ld_mlp_words_per_drone",
                         "ld_genome_words"):
             getattr(h, name).restype = C.c_int
+
+
+_specialised = {}          # hidden widths -> CDLL of the run-time specialisation (kept alive: the registry holds its entry points)
+
+
+def specialise(hidden) -> bool:
+    """Make the unrolled float32 kernels available for one more layer spec: compile them with hipcc
+    (build.build_specialisation; cached under build/jit/), load the object and register it with the library
+    (ld_register_specialisation_f32).  Returns True if the spec now runs unrolled kernels (also when it always
+    did), raises if hipcc fails.  Results do not change (same arithmetic as the generic kernels, bit for
+    bit); throughput does: 47-68 % -> 85-90 % of the HBM roofline."""
+    from . import build as ld_build
+    spec = MlpSpec.from_hidden(hidden)
+    key = spec.hidden_widths
+    h = lib()
+    if h.ld_has_specialisation_f32(C.byref(spec)) == 1:
+        return True
+    so = C.CDLL(str(ld_build.build_specialisation(key)))
+    fly = C.cast(so.ld_spec_fly_steps_f32, C.c_void_p)
+    mlp = C.cast(so.ld_spec_mlp_forward_f32, C.c_void_p)
+    check(h.ld_register_specialisation_f32(C.byref(spec), fly, mlp), "ld_register_specialisation_f32")
+    _specialised[key] = so
+    return True
 
 
 def check(status: int, what: str) -> None:
@@ -130,5 +155,5 @@ def require_gpu() -> None:
         raise RuntimeError("learning-drones_amd needs a HIP device (MI355X); none is visible and there is no CPU fallback")
 
 
-__all__ = ["lib", "check", "require_gpu", "EXPORTS", "LIB_PATH", "NativeLibraryMissing", "LdError",
+__all__ = ["lib", "check", "require_gpu", "specialise", "EXPORTS", "LIB_PATH", "NativeLibraryMissing", "LdError",
            "FitnessRecord"]

@@ -2,6 +2,7 @@
 // specialisations (ld_unrolled_*.hip) or the generic kernels, and the small kernels' launches.
 #include <atomic>
 #include <cstdlib>
+#include <mutex>
 
 #include "ld_ga.hpp"
 #include "ld_kernels.hpp"
@@ -26,6 +27,34 @@ using ld::launch_mlp;
 namespace {
 
 std::atomic<int> g_force_generic{0};          // ld_debug_force_generic: the library's only process-wide state
+
+// Specs specialised at run time (ld_register_specialisation_f32): the library's other process-wide state.
+struct Specialisation {
+    ld_mlp_spec spec;
+    ld_fly_steps_f32_fn fly_steps;
+    ld_mlp_forward_f32_fn mlp_forward;
+};
+constexpr int kMaxSpecialisations = 64;
+Specialisation g_specialisations[kMaxSpecialisations];
+std::atomic<int> g_n_specialisations{0};               // entries below this index are complete and never change
+std::mutex g_specialisations_mutex;
+
+bool same_spec(const ld_mlp_spec& a, const ld_mlp_spec& b)
+{
+    if (a.n_hidden != b.n_hidden) return false;
+    for (int i = 0; i < a.n_hidden; ++i)
+        if (a.hidden[i] != b.hidden[i]) return false;
+    return true;
+}
+
+const Specialisation* find_specialisation(const ld_mlp_spec& spec)
+{
+    if (g_force_generic.load(std::memory_order_relaxed)) return nullptr;
+    const int count = g_n_specialisations.load(std::memory_order_acquire);
+    for (int i = 0; i < count; ++i)
+        if (same_spec(g_specialisations[i].spec, spec)) return &g_specialisations[i];
+    return nullptr;
+}
 
 int check_spec(const ld_mlp_spec* spec)
 {
@@ -81,6 +110,9 @@ int dispatch_mlp(const ld_mlp_spec* spec, const Real* genomes, const Real* input
         LD_FOR_EACH_UNROLLED(X)
 #undef X
     }
+    if constexpr (sizeof(Real) == 4) {
+        if (const Specialisation* s = find_specialisation(*spec)) return s->mlp_forward(spec, genomes, inputs, outputs, n, stream);
+    }
     return launch_mlp<Real, ld::GenericNet<Real, Fma>>(spec, genomes, inputs, outputs, n, stream);
 }
 
@@ -110,12 +142,22 @@ int dispatch_split_f32(const ld_sim_params* sim, const ld_episode_params* ep, co
         return ld_u_split_f32_##TAG(sim, ep, coins, walls, genomes, fstate, istate, n, n_steps, waves, stream);
     LD_FOR_EACH_UNROLLED(X)
 #undef X
+    if (const Specialisation* s = find_specialisation(*spec))
+        return s->fly_steps(sim, ep, coins, walls, genomes, fstate, istate, n, n_steps, waves, stream);
     return LD_ERR_SPEC;
 }
 
 bool has_unrolled(const ld_mlp_spec& spec)
 {
     if (g_force_generic.load(std::memory_order_relaxed)) return false;
+#define X(TAG, ...) if (spec_is<__VA_ARGS__>(spec)) return true;
+    LD_FOR_EACH_UNROLLED(X)
+#undef X
+    return find_specialisation(spec) != nullptr;
+}
+
+bool has_builtin_unrolled(const ld_mlp_spec& spec)
+{
 #define X(TAG, ...) if (spec_is<__VA_ARGS__>(spec)) return true;
     LD_FOR_EACH_UNROLLED(X)
 #undef X
@@ -410,6 +452,29 @@ int ld_ga_breed_f64(const ld_ga_params* ga, const ld_mlp_spec* spec, const doubl
 int ld_version(void) { return LD_ABI_VERSION; }
 
 int ld_debug_force_generic(int on) { return g_force_generic.exchange(on ? 1 : 0); }
+
+int ld_register_specialisation_f32(const ld_mlp_spec* spec, ld_fly_steps_f32_fn fly_steps, ld_mlp_forward_f32_fn mlp_forward)
+{
+    const int rc = check_spec(spec);
+    if (rc) return rc;
+    if (!fly_steps || !mlp_forward) return LD_ERR_NULL;
+    if (has_builtin_unrolled(*spec)) return LD_ERR_SIZE;
+    std::lock_guard<std::mutex> lock(g_specialisations_mutex);
+    const int count = g_n_specialisations.load(std::memory_order_relaxed);
+    for (int i = 0; i < count; ++i)
+        if (same_spec(g_specialisations[i].spec, *spec)) return LD_ERR_SIZE;
+    if (count >= kMaxSpecialisations) return LD_ERR_SIZE;
+    g_specialisations[count] = Specialisation{*spec, fly_steps, mlp_forward};
+    g_n_specialisations.store(count + 1, std::memory_order_release);
+    return LD_OK;
+}
+
+int ld_has_specialisation_f32(const ld_mlp_spec* spec)
+{
+    const int rc = check_spec(spec);
+    if (rc) return rc;
+    return has_unrolled(*spec) ? 1 : 0;
+}
 
 int ld_accelerations_f32(const ld_sim_params* sim, const float* angle, const float* thrust, float* lin_acc, float* rot_acc,
                          int64_t n, void* stream)

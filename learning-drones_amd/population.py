@@ -40,10 +40,13 @@ class Population:
                  device: Optional[str] = None, sim: Optional[SimParams] = None,
                  episode: Optional[EpisodeParams] = None, coins: Optional[np.ndarray] = None,
                  walls: Optional[np.ndarray] = None, init_state: Optional[Sequence[float]] = None,
-                 coin_respawn: Optional[bool] = None):
+                 coin_respawn: Optional[bool] = None, specialise: bool = False):
         """coins=None is the reference's episode: the first coin (5, 5, 10) and the unbounded respawn
         chain behind it (flight/__init__.py:25,47-52).  A coin table given explicitly is a finite chain
-        (nothing respawns after its last row) unless coin_respawn=True continues it by the reference rule."""
+        (nothing respawns after its last row) unless coin_respawn=True continues it by the reference rule.
+        specialise=True compiles the unrolled float32 kernels for this layer spec if the library does not ship
+        them (_native.specialise: hipcc at first use, cached; identical results, about twice the throughput of
+        the run-time-spec kernels)."""
         torch = _torch()
         _native.require_gpu()
         if precision not in ("f32", "f64"):
@@ -52,6 +55,8 @@ class Population:
         if self.n < 0:
             raise ValueError("n must be >= 0")
         self.spec = hidden if isinstance(hidden, MlpSpec) else MlpSpec.from_hidden(hidden)
+        if specialise and precision == "f32":
+            _native.specialise(self.spec.hidden_widths)
         self.precision = precision
         self.dtype = torch.float32 if precision == "f32" else torch.float64
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")

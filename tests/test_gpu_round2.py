@@ -435,3 +435,35 @@ def test_closed_loop_f64_resident_tracks_reference(Population, g3):
             assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)) < 1e-8, ei
         seen += 1
     assert seen >= 40
+
+
+# ------------------------------------------------------------------------------------------- run-time specialisation
+@pytest.mark.parametrize("hidden", [(12, 12), (20, 20), (5, 9, 3)])
+def test_runtime_specialised_spec_equals_generic_kernels(Population, torch, generic_kernels, hidden):
+    """Population(..., specialise=True) compiles the unrolled kernels for a spec the library does not ship
+    (hipcc at first use) and registers them; every launch geometry of the specialised kernels, and
+    feed_forward, must reproduce the run-time-spec kernels bit for bit."""
+    from test_gpu_parity import _mixed_genomes
+    n, T = 200, 300
+    spec, genes, cls = _mixed_genomes(hidden, n, seed=17)
+    x = np.random.default_rng(2).normal(0, 3, (15, n))
+    generic_kernels(True)
+    ref = Population(n, hidden)
+    ref.set_genomes(genes)
+    y_ref = ref.feed_forward(x).clone()
+    for _ in range(T):
+        ref.step()
+    ref.finalize()
+    generic_kernels(False)
+    pop = Population(n, hidden, specialise=True)
+    assert pop.rollout_geometry(T)["steps_per_launch"] == 16
+    pop.set_genomes(genes)
+    assert torch.equal(pop.feed_forward(x), y_ref)
+    pop.fly(T)
+    assert torch.equal(pop.fstate, ref.fstate) and torch.equal(pop.istate, ref.istate) and torch.equal(pop.records, ref.records)
+    for waves, k in ((1, 1), (2, 7), (8, 300)):
+        pop.reset()
+        pop.fly(T, steps_per_launch=k, waves_per_block=waves)
+        assert torch.equal(pop.records, ref.records), (waves, k)
+    crashed = (ref.istate[2] & 1).bool()
+    assert crashed.any() and not crashed.all()

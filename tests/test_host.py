@@ -197,3 +197,31 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ld_genome_words(C.byref(spec), -1) == SIZE
     for code in (0, -1, -2, -3, -4, -5, -6, -99):
         assert lib.ld_strerror(code)
+
+
+def test_runtime_specialisation_builds_and_registers(lib):
+    """learning_drones_amd.specialise(): hipcc builds the unrolled float32 kernels for one more layer spec
+    (cross-compiles without a GPU), the object exports the two entry points, and the library's registry takes
+    them once; specs with a built-in specialisation, NULL entry points and duplicates are refused."""
+    from learning_drones_amd import build as ld_build
+    spec = MlpSpec.from_hidden((13, 7))
+    assert lib.ld_has_specialisation_f32(C.byref(spec)) == 0
+    assert lib.ld_has_specialisation_f32(C.byref(MlpSpec.from_hidden((32, 32)))) == 1
+    so_path = ld_build.build_specialisation((13, 7))
+    assert so_path.exists() and ld_build.build_specialisation((13, 7)) == so_path            # cached
+    so = C.CDLL(str(so_path))
+    fly, mlp = C.cast(so.ld_spec_fly_steps_f32, C.c_void_p), C.cast(so.ld_spec_mlp_forward_f32, C.c_void_p)
+    assert lib.ld_register_specialisation_f32(C.byref(spec), None, mlp) == -1
+    assert lib.ld_register_specialisation_f32(C.byref(MlpSpec.from_hidden((32, 32))), fly, mlp) == -3      # ships unrolled
+    assert _native.specialise((13, 7)) is True and lib.ld_has_specialisation_f32(C.byref(spec)) == 1
+    assert lib.ld_register_specialisation_f32(C.byref(spec), fly, mlp) == -3                                 # already there
+    assert _native.specialise((13, 7)) is True and _native.specialise((16, 16)) is True                       # no-ops
+    k, w, m = C.c_int32(), C.c_int32(), C.c_int32()
+    assert lib.ld_fly_rollout_geometry_f32(C.byref(spec), 8192, 2000, C.byref(k), C.byref(w), C.byref(m)) == 0
+    assert (k.value, w.value, m.value) == (16, 8, 125)                   # the specialised spec takes the multi-step geometry
+    assert lib.ld_debug_force_generic(1) == 0 and lib.ld_has_specialisation_f32(C.byref(spec)) == 0
+    assert lib.ld_debug_force_generic(0) == 1
+    # the entry points validate like the built-in ones (n == 0 is a no-op, no kernel is launched without a GPU)
+    sim, ep = SimParams.reference(), EpisodeParams.reference(n_coins=1)
+    fake = C.c_void_p(0x1000)
+    assert lib.ld_fly_steps_f32(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, 0, 4, 0, None) == 0

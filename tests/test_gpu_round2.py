@@ -438,7 +438,7 @@ def test_closed_loop_f64_resident_tracks_reference(Population, g3):
 
 
 # ------------------------------------------------------------------------------------------- run-time specialisation
-@pytest.mark.parametrize("hidden", [(12, 12), (20, 20), (5, 9, 3)])
+@pytest.mark.parametrize("hidden", [(12, 12), (20, 20), (9, 13, 11)])
 def test_runtime_specialised_spec_equals_generic_kernels(Population, torch, generic_kernels, hidden):
     """Population(..., specialise=True) compiles the unrolled kernels for a spec the library does not ship
     (hipcc at first use) and registers them; every launch geometry of the specialised kernels, and

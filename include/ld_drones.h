@@ -375,9 +375,8 @@ int ld_ga_select(const ld_ga_params *ga, const ld_mlp_spec *spec, const int32_t 
  * dst is the children's genome array (n_children drones, same blocked layout); it must not alias src.
  * order (device, int32[n_children], or NULL = identity) places child order[s] of this shard into genome
  * slot s.  A child's parents, cut points and random draws are keyed by the CHILD index, so every
- * placement produces the same set of children; the GA driver sorts the children by the slot of their
- * first parent (elite first), which makes the gather of 16-byte parent words below read neighbouring
- * lines instead of 64 scattered ones per wavefront.  order must be a permutation of 0..n_children-1. */
+ * placement produces the same set of children (a driver may sort them, e.g. by parent slot for gather
+ * locality or by expected lifetime).  order must be a permutation of 0..n_children-1. */
 int ld_ga_breed_f32(const ld_ga_params *ga, const ld_mlp_spec *spec, const float *src, int64_t n_per_segment,
                     int32_t n_segments, const int32_t *parents, const int32_t *cuts, const float *elite,
                     int64_t child_begin, int64_t n_children, const int32_t *order, float *dst, void *stream);

@@ -335,12 +335,11 @@ class Population:
         Placement of the children (ld_ga_breed's `order`; a child's parents, cuts and mutation draws are keyed
         by the child, so any placement produces the same set of children, and the reference attaches no
         meaning to list positions beyond slot 0: evolve/util.py:5-27, evolve/evolution.py:89-107):
-        place="parent" sorts the children by the slot of their first parent, which turns the kernel's gather
-        of 16-byte parent words from 64 scattered 1 KiB lines per wavefront into a read of one or two
-        neighbouring lines; lifetimes (int32 device tensor, flight_time of ALL n_total drones of the
-        generation just flown) sorts them by that parent's flight time instead, longest first -- measured to
-        be worth 8 % of a rollout's masked work (a child's lifetime barely follows its parent's), and nothing
-        since the resident kernel hands drones out from a work queue.  The elite stays in slot 0 either way.
+        place="parent" sorts the children by the slot of their first parent (neighbouring reads in the kernel's
+        gather of 16-byte parent words); lifetimes (int32 device tensor, flight_time of ALL n_total drones of
+        the generation just flown) sorts them by that parent's flight time instead, longest first.  Neither
+        pays at present (see DeviceEvolution): the breed kernel is bound by its random-number arithmetic and
+        the resident kernel balances lifetimes itself.  The elite stays in slot 0 either way.
 
         slot_of: optional int64 device tensor [n_total]: the genome slot that holds the drone with canonical
         index i.  Selection always works on canonical indices (fitness_all is then in canonical order and the

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Every profile of the round on one GPU box (rocprofv3 kernel traces, FETCH_SIZE / WRITE_SIZE passes, GRBM clock pass,
+# SQ counters), outputs under gpurun_out/prof/.  Summaries are written by scripts/profile_summary.py afterwards.
+set -e
+cd "$(dirname "$0")/.."
+out=$PWD/gpurun_out/prof
+mkdir -p $out
+export TMPDIR=/tmp
+scripts/profile_config.sh c3                                                       # BASELINE config 3 (headline)
+scripts/profile_config.sh c3_k1 --steps-per-launch 1 --waves-per-block 1           # the literal contract: one launch per timestep
+scripts/profile_config.sh shard8 --drones 8192                                     # 65 536-drone population over 8 GPUs: one shard
+scripts/profile_config.sh c4 --drones 32768 --timesteps 4000                       # config 4 shard
+scripts/profile_config.sh c2 --drones 1024 --hidden 16,16 --coins 1                # config 2
+scripts/profile_config.sh c5 --drones 131072 --timesteps 400 --hidden 64,64,64 --coins 5   # config 5 shard (short episode)
+scripts/profile_config.sh gen12 --hidden 12,12                                     # run-time-spec kernel
+scripts/profile_config.sh jit12 --hidden 12,12 --specialise                        # the same spec specialised at run time
+# effective shader clock of the profiled headline run: GRBM_GUI_ACTIVE / 8 / kernel duration
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/c3_clock -- python3 bench.py --steps 1 --warmup 0 --no-extras > $out/c3_clock.json 2> $out/c3_clock.err
+# the whole default bench (resident engine, GA kernels, random-init population): trace, then SQ counters
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/full_trace -- python3 bench.py --no-cpu-baseline > $out/full_trace.json 2> $out/full_trace.err
+find $out/full_trace -name '*kernel_trace.csv' -delete
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --output-format csv -d $out/full_sq -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/full_sq.json 2> $out/full_sq.err
+echo "all profiled"; du -sh $out

@@ -447,7 +447,12 @@ class Population:
             log[t] = self.fstate.index_select(1, idx)
             coin[t] = self.istate[I_COINS].index_select(0, idx)
         a = log.permute(2, 0, 1).double().cpu().numpy()
-        target = self.coins_host[np.minimum(coin.t().cpu().numpy(), len(self.coins_host) - 1)][:, :, :3]
+        k, last = coin.t().cpu().numpy(), len(self.coins_host) - 1
+        target = self.coins_host[np.minimum(k, last)][:, :, :3].copy()
+        if self.episode.coin_respawn:                                     # beyond the table: flight/__init__.py:47-52
+            extra = np.maximum(k - last, 0)
+            target[:, :, 0] += 5.0 * extra
+            target[:, :, 1] += 2.5 * extra
         out = np.zeros((len(idx), T, 25))
         out[:, :, 0] = np.arange(T)[None, :] * float(self.sim.dt)
         out[:, :, 1:4] = np.degrees(a[:, :, F_ANGLE:F_ANGLE + 3])

@@ -114,6 +114,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline rollout and its roofline (for rocprofv3 "
                     "runs: keeps every fused launch in the trace a full, live-population launch of the headline geometry)")
+    ap.add_argument("--exchange", default="allgather", choices=("allgather", "alltoall"), help="parent-genome exchange of the "
+                    "generation step when N > 1: all-gather of the genome shards (the default here: the two most ordinary "
+                    "collectives, so that an unproven path cannot cost the scaling record) or the all-to-all of exactly the "
+                    "selected parents (1/N of the bytes; unverified on RCCL until a multi-GPU record exists)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets several ranks share one "
                     "GPU to rehearse the N > 1 control flow on a one-GPU box")
     args = ap.parse_args()
@@ -131,10 +135,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        limit = datetime.timedelta(minutes=5)      # a wedged collective ends the job in minutes, not at the default 10+
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=limit)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=limit)
         # bring the communicator up before anything is timed (also when --warmup 0)
         dist.all_reduce(torch.zeros(1, device=device))
         torch.cuda.synchronize()
@@ -296,9 +302,11 @@ def main():
     # HBM bytes per launch from the PMC counters and the profiled launch duration: collected by separate
     # rocprofv3 passes of this same command and committed under profiles/ (they cannot be read live);
     # used only when the profiled launch configuration is the one being run.
-    for f in sorted((REPO / "profiles").glob("r*_fly_step_pmc.json"), reverse=True):
+    for f in sorted((REPO / "profiles").glob("r*_pmc.json"), reverse=True):
         prof = json.loads(f.read_text())
-        cfg = prof["config"]
+        cfg = prof.get("config")
+        if not cfg or "hbm_traffic_bytes_per_launch" not in prof:
+            continue
         if (cfg["drones"] == n_local and tuple(cfg["hidden"]) == hidden and cfg["coins"] == args.coins
                 and cfg.get("timesteps_per_launch", 1) == roof["timesteps_per_launch"]
                 and cfg.get("wavefronts_per_block", 1) == roof["wavefronts_per_block"]):
@@ -332,7 +340,7 @@ def main():
     # crash early and frozen blocks skip their gene traffic, so this is faster than 1 / episode time; the
     # live fraction of the measured generations is reported next to it.
     from learning_drones_amd.parallel import DeviceEvolution
-    evo = DeviceEvolution(pop, seed=0x1D20)
+    evo = DeviceEvolution(pop, seed=0x1D20, exchange=args.exchange)
     n_gen, gen_live, gen_dt, gen_error = 3, 0.0, float("nan"), ("skipped (--no-extras)" if args.no_extras else None)
     if not args.no_extras:
         ok = 1
@@ -348,20 +356,17 @@ def main():
             gen_dt = max_over_ranks(time.perf_counter() - g0)
         except RuntimeError as err:      # reported, and fatal for the whole job below (no rank may carry on alone)
             gen_error, ok = str(err)[:200], 0
-        if dist:
+        if dist:                         # every rank learns whether ANY rank failed: nobody carries on alone
             flag = torch.tensor([ok], dtype=torch.int64, device=device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
-                if rank == 0:
-                    print(json.dumps({"error": "generation step failed on at least one rank", "detail": gen_error}), flush=True)
-                dist.destroy_process_group()
-                raise SystemExit(3)
-        elif not ok:
-            raise SystemExit(f"generation step failed: {gen_error}")
+                gen_error = gen_error or "the generation step failed on another rank"
+        if gen_error:                    # the headline above stands; the line reports generations_per_s null + the error
+            print(f"[bench] rank {rank}: generation step failed: {gen_error}", file=sys.stderr, flush=True)
     # the generation step's own kernels (select + breed, no communication): local shard bred from itself
     from learning_drones_amd.params import GaParams
     breed_ms = breed_gbs = None
-    if not args.no_extras:
+    if not args.no_extras and not gen_error:
         fit_local = pop.local.records[:, 0].contiguous()
         b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         pop.local.breed(fit_local, GaParams.reference(seed=3))

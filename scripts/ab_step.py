@@ -11,7 +11,7 @@ if alt: sys.argv.remove('--alt')
 n = int(sys.argv[1]); hidden = tuple(int(h) for h in sys.argv[2].split(',')); libs = sys.argv[3:]
 spec = MlpSpec.from_hidden(hidden); P, W = spec.param_count, spec.words_per_drone
 dev = torch.device('cuda:0')
-sim, ep = SimParams.reference(), EpisodeParams.reference(n_coins=3)
+sim, ep = SimParams.reference(), EpisodeParams.reference(n_coins=3, coin_respawn=False)
 coins = torch.from_numpy(coin_chain_reference(3)).to(dev)
 rows = bench.make_genomes(torch, n, hidden, dev, 0)
 fstate = torch.zeros((22, n), dtype=torch.float32, device=dev); istate = torch.zeros((3, n), dtype=torch.int32, device=dev)
@@ -37,8 +37,7 @@ res = {k: [] for k in handles}
 L = 200
 for rnd in range(7):
     for name, h in handles.items():
-        if name.endswith(':generic'): os.environ['LD_FORCE_GENERIC'] = '1'
-        else: os.environ.pop('LD_FORCE_GENERIC', None)
+        h.ld_debug_force_generic(1 if name.endswith(':generic') else 0)
         reset()
         for _ in range(10): step(h)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,11 +1,14 @@
-"""Soak test: the resident engine against the step engine on randomly drawn populations (sizes,
-layer specs, episode lengths, coin-table lengths, wall boxes, initial states).  Any difference in
-state, bookkeeping or records is an error.  usage: soak_engines.py [rounds]"""
+"""Soak test: every engine and launch geometry against the run-time-spec step kernel on randomly drawn
+populations (sizes, layer specs, episode lengths, coin tables with and without the respawn rule, wall
+boxes, wind, initial states): the default rollout (16 timesteps per launch, wavefronts per block chosen
+from n), a random (wavefronts per block, timesteps per launch) pair, and the work-queue resident engine.
+Any difference in state, bookkeeping or records is an error.  usage: soak_engines.py [rounds]"""
 import sys
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np, torch
 from learning_drones_amd.population import Population
-from learning_drones_amd.params import coin_chain_reference
+from learning_drones_amd import _native
+from learning_drones_amd.params import SimParams, coin_chain_reference
 from test_gpu_parity import _mixed_genomes
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
@@ -23,15 +26,25 @@ for r in range(rounds):
     init = np.array([rng.normal(0, 2), rng.normal(0, 2), rng.uniform(5, 40), *rng.normal(0, 1, 3), *rng.normal(0, 0.2, 3), *rng.normal(0, 1, 3)])
     spec, genes, cls = _mixed_genomes(hidden, max(n, 3), seed=1000 + r)
     genes = genes[:n]
+    respawn = bool(rng.random() < 0.5)
+    sim = SimParams.reference(wind=rng.normal(0, 0.5, 3)) if rng.random() < 0.3 else None
+    waves, k = int(rng.choice([1, 2, 4, 8])), int(rng.choice([1, 3, 16, 50, T]))
     out = []
-    for engine in ("step", "resident"):
-        pop = Population(n, hidden, coins=coins, walls=walls, init_state=init)
+    for kw in ("generic", dict(), dict(steps_per_launch=k, waves_per_block=waves), dict(engine="resident")):
+        pop = Population(n, hidden, coins=coins, walls=walls, init_state=init, coin_respawn=respawn, sim=sim)
         pop.set_genomes(genes)
-        pop.fly(T, engine=engine)
+        if kw == "generic":
+            _native.lib().ld_debug_force_generic(1)
+            for _ in range(T):
+                pop.step()
+            pop.finalize()
+            _native.lib().ld_debug_force_generic(0)
+        else:
+            pop.fly(T, **kw)
         out.append((pop.fstate.clone(), pop.istate.clone(), pop.records.clone()))
-    same = all(torch.equal(a, b) for a, b in zip(*out))
+    same = all(torch.equal(a, b) for other in out[1:] for a, b in zip(out[0], other))
     crashed = float((out[0][1][2] & 1).float().mean())
-    print(f"round {r:3d} spec {str(hidden):14s} n={n:5d} T={T:5d} coins={len(coins):2d} walls={0 if walls is None else len(walls):2d} crashed {crashed:.2f}  {'ok' if same else 'MISMATCH'}", flush=True)
+    print(f"round {r:3d} spec {str(hidden):14s} n={n:5d} T={T:5d} coins={len(coins):2d}{'+' if respawn else ' '} L={waves} K={k:4d} walls={0 if walls is None else len(walls):2d} crashed {crashed:.2f}  {'ok' if same else 'MISMATCH'}", flush=True)
     bad += not same
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)

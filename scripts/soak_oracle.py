@@ -32,8 +32,9 @@ for r in range(rounds):
     base = controllers.hover_net(hidden)
     genes = np.stack([np.concatenate([w.ravel() for w in controllers.perturbed(base, 0.002 * (i % 4), rng)]) if i % 2 == 0
                       else np.concatenate([rng.normal(0, 1 / np.sqrt(a), a * b) for a, b in spec.layer_shapes]) for i in range(n)])
-    ep = EpisodeParams.reference(n_coins=len(coins), n_walls=0 if walls is None else len(walls))
-    pop = Population(n, hidden, precision="f64", coins=coins, walls=walls, sim=sim, init_state=init)
+    pop = Population(n, hidden, precision="f64", coins=coins, walls=walls, sim=sim, init_state=init,
+                     coin_respawn=bool(rng.random() < 0.5))
+    ep = pop.episode
     pop.set_genomes(genes)
     pop.fly(T)
     got = pop.results()

@@ -205,7 +205,7 @@ def main():
         achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "kernel": ("fly_split_kernel<float, L=%d, %s>" % (geo["waves_per_block"], "-".join(map(str, hidden)))
-                           if geo["steps_per_launch"] > 1 or geo["waves_per_block"] > 1 or hidden in pop.local.RESIDENT_SPECS
+                           if geo["steps_per_launch"] > 1 or geo["waves_per_block"] > 1 or pop.local.has_resident_engine()
                            else "fly_step_kernel<float, GenericNet> (run-time layer spec)"),
                 "bytes_per_launch": bytes_per_launch, "launch_us": launch_ms * 1e3,
                 "timesteps_per_launch": geo["steps_per_launch"], "wavefronts_per_block": geo["waves_per_block"],
@@ -285,7 +285,7 @@ def main():
     # and crashes within a few hundred steps; frozen blocks skip their gene traffic, so an episode
     # costs far less than N*T full drone-steps.  Informational (live drone-steps only are real work).
     random_pop = {}
-    engines = () if args.no_extras else (("step", "resident") if hidden in pop.local.RESIDENT_SPECS else ("step",))
+    engines = () if args.no_extras else (("step", "resident") if pop.local.has_resident_engine() else ("step",))
     if engines:
         pop.local.init_genomes_reference(seed=7 + rank)
     for engine in engines:
@@ -320,7 +320,7 @@ def main():
     # The genome-resident engine (one launch per episode, genes held in registers: beyond the contract
     # of streaming the genes every timestep, bit-identical results) on the same workload, for reference.
     resident = None
-    if hidden in pop.local.RESIDENT_SPECS and not args.no_extras:
+    if pop.local.has_resident_engine() and not args.no_extras:
         pop.local.reset()
         pop.fly(T, engine="resident")
         fence()

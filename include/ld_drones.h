@@ -321,7 +321,7 @@ int ld_fly_steps_resident_f32(const ld_sim_params *sim, const ld_episode_params 
  * HBM roofline where the unrolled ones reach 85-90 %.  A host program that has hipcc can compile the
  * unrolled kernels for one more spec (learning_drones_amd.build.build_specialisation writes a ten-line
  * translation unit that instantiates csrc/ld_split.inc and csrc/ld_unrolled.inc for the spec, builds it
- * into its own shared object and loads it) and register its two entry points here; from then on
+ * into its own shared object and loads it) and register its entry points here; from then on
  * ld_fly_step_f32 / ld_fly_steps_f32 / ld_fly_rollout_f32 / ld_fly_rollout_steps_f32 / ld_mlp_forward_f32
  * dispatch that spec to them (same arithmetic: results are bit-identical to the generic kernels).
  * The registry is process-wide (at most 64 specs, guarded by a mutex); the generic kernels stay the
@@ -333,11 +333,20 @@ typedef int (*ld_fly_steps_f32_fn)(const ld_sim_params *sim, const ld_episode_pa
                                    int64_t n, int32_t n_steps, int32_t waves_per_block, void *stream);
 typedef int (*ld_mlp_forward_f32_fn)(const ld_mlp_spec *spec, const float *genomes, const float *inputs,
                                      float *outputs, int64_t n, void *stream);
+/* n_steps iterations of the genome-resident kernel, no finalize (what ld_fly_steps_resident_f32 runs). */
+typedef int (*ld_fly_resident_f32_fn)(const ld_sim_params *sim, const ld_episode_params *ep, const double *coins,
+                                      const double *walls, const float *genomes, float *fstate, int32_t *istate,
+                                      int64_t n, int32_t n_steps, int32_t *queue, void *stream);
+/* fly_resident may be NULL: the spec then has no resident engine (ld_fly_rollout_resident_f32 returns
+ * LD_ERR_SPEC for it, as for any spec without one). */
 int ld_register_specialisation_f32(const ld_mlp_spec *spec, ld_fly_steps_f32_fn fly_steps,
-                                   ld_mlp_forward_f32_fn mlp_forward);
+                                   ld_mlp_forward_f32_fn mlp_forward, ld_fly_resident_f32_fn fly_resident);
 /* 1 if ld_fly_step_f32 takes an unrolled kernel for this spec (built in or registered), 0 if the generic
  * kernel, negative ld_status for an invalid spec. */
 int ld_has_specialisation_f32(const ld_mlp_spec *spec);
+/* 1 if ld_fly_rollout_resident_f32 / _f64 can run this spec (built in or, float32, registered), else 0. */
+int ld_has_resident_f32(const ld_mlp_spec *spec);
+int ld_has_resident_f64(const ld_mlp_spec *spec);
 
 /* ---------------------------------------------------------------------------------------------
  * Generation step on the device: the GA operators of evolve/util.py:5-78 and

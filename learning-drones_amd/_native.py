@@ -28,6 +28,7 @@ EXPORTS = (
     "ld_fly_rollout_resident_f32", "ld_debug_force_generic", "ld_accelerations_f32", "ld_accelerations_f64",
     "ld_fly_steps_f32", "ld_fly_rollout_steps_f32", "ld_fly_rollout_geometry_f32", "ld_fly_steps_resident_f32",
     "ld_fly_rollout_resident_f64", "ld_register_specialisation_f32", "ld_has_specialisation_f32",
+    "ld_has_resident_f32", "ld_has_resident_f64",
 )
 ABI_VERSION = 2
 
@@ -100,8 +101,10 @@ def _declare(h: C.CDLL) -> None:
     h.ld_accelerations_f32.argtypes = [sim, vp, vp, vp, vp, i64, vp]
     h.ld_accelerations_f64.argtypes = [sim, vp, vp, vp, vp, i64, vp]
     h.ld_debug_force_generic.argtypes = [C.c_int]
-    h.ld_register_specialisation_f32.argtypes = [spec, vp, vp]
+    h.ld_register_specialisation_f32.argtypes = [spec, vp, vp, vp]
     h.ld_has_specialisation_f32.argtypes = [spec]
+    h.ld_has_resident_f32.argtypes = [spec]
+    h.ld_has_resident_f64.argtypes = [spec]
     h.ld_fly_steps_resident_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, i64, i32, vp, vp]
     pi32 = C.POINTER(C.c_int32)
     h.ld_fly_rollout_geometry_f32.argtypes = [spec, i64, i32, pi32, pi32, pi32]
@@ -135,7 +138,8 @@ def specialise(hidden) -> bool:
     so = C.CDLL(str(ld_build.build_specialisation(key)))
     fly = C.cast(so.ld_spec_fly_steps_f32, C.c_void_p)
     mlp = C.cast(so.ld_spec_mlp_forward_f32, C.c_void_p)
-    check(h.ld_register_specialisation_f32(C.byref(spec), fly, mlp), "ld_register_specialisation_f32")
+    res = C.cast(so.ld_spec_fly_resident_f32, C.c_void_p) if hasattr(so, "ld_spec_fly_resident_f32") else None
+    check(h.ld_register_specialisation_f32(C.byref(spec), fly, mlp, res), "ld_register_specialisation_f32")
     _specialised[key] = so
     return True
 

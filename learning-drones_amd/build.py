@@ -91,19 +91,36 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 JIT_DIR = OBJ_DIR / "jit"
 
 
+def resident_lanes(hidden) -> int:
+    """Lanes per drone for the genome-resident kernel of a spec specialised at run time: the smallest power of
+    two that leaves at most ~160 gene registers per lane (two wavefronts per SIMD), the regime the built-in
+    specs' measured optima sit in (profiles/r02_resident_lanes.json); 0 if even 64 lanes do not fit."""
+    n_in, genes = 15, 0
+    for h in tuple(hidden) + (4,):
+        genes += h * (n_in + 1)
+        n_in = h
+    lanes = 2
+    while lanes < 64 and genes / lanes > 160:
+        lanes *= 2
+    return lanes if genes / lanes <= 230 else 0
+
+
 def build_specialisation(hidden, verbose: bool = False) -> Path:
-    """Compile the unrolled float32 kernels (fused step in every launch geometry + feed_forward) for ONE more
-    layer spec into its own shared object, build/jit/libld_spec_<widths>.so, and return its path.  The
-    translation unit is ten lines: it instantiates csrc/ld_split.inc and csrc/ld_unrolled.inc for the spec and
-    exports the two C entry points ld_register_specialisation_f32 takes.  Needs hipcc (20-60 s for nets up to
-    ~3 000 genes; the object is reused afterwards)."""
+    """Compile the unrolled float32 kernels (fused step in every launch geometry, feed_forward, and the
+    genome-resident engine where the genome fits in registers) for ONE more layer spec into its own shared
+    object, build/jit/libld_spec_<widths>.so, and return its path.  The translation unit is a dozen lines: it
+    instantiates csrc/ld_split.inc, csrc/ld_unrolled.inc and ld::launch_fly_resident for the spec and exports
+    the C entry points ld_register_specialisation_f32 takes.  Needs hipcc (20-60 s for nets up to ~3 000
+    genes; the object is reused afterwards)."""
     hidden = tuple(int(h) for h in hidden)
     tag = "_".join(map(str, hidden))
+    widths = ", ".join(map(str, hidden))
+    lanes = resident_lanes(hidden)
     JIT_DIR.mkdir(parents=True, exist_ok=True)
     src, lib = JIT_DIR / f"ld_spec_{tag}.hip", JIT_DIR / f"libld_spec_{tag}.so"
     text = (f"// generated by learning_drones_amd.build.build_specialisation({hidden})\n"
-            f"#define LD_TAG jit_{tag}\n#define LD_WIDTHS {', '.join(map(str, hidden))}\n#define LD_ONLY_F32\n"
-            f'#include "{CSRC}/ld_unrolled.inc"\n#undef LD_CAT_\n#undef LD_CAT\n#include "{CSRC}/ld_split.inc"\n'
+            f"#define LD_TAG jit_{tag}\n#define LD_WIDTHS {widths}\n#define LD_ONLY_F32\n"
+            f'#include "{CSRC}/ld_unrolled.inc"\n#include "{CSRC}/ld_split.inc"\n#include "{CSRC}/ld_resident.hpp"\n'
             'extern "C" int ld_spec_fly_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, const double* coins, '
             "const double* walls, const float* genomes, float* fstate, int32_t* istate, int64_t n, int32_t n_steps, "
             "int32_t waves_per_block, void* stream)\n"
@@ -112,6 +129,12 @@ def build_specialisation(hidden, verbose: bool = False) -> Path:
             'extern "C" int ld_spec_mlp_forward_f32(const ld_mlp_spec* spec, const float* genomes, const float* inputs, '
             "float* outputs, int64_t n, void* stream)\n"
             f"{{ return ld_u_mlp_f32_jit_{tag}(spec, genomes, inputs, outputs, n, static_cast<hipStream_t>(stream)); }}\n")
+    if lanes:
+        text += ('extern "C" int ld_spec_fly_resident_f32(const ld_sim_params* sim, const ld_episode_params* ep, const double* coins, '
+                 "const double* walls, const float* genomes, float* fstate, int32_t* istate, int64_t n, int32_t n_steps, "
+                 "int32_t* queue, void* stream)\n"
+                 f"{{ return ld::launch_fly_resident<float, false, {lanes}, {widths}>(sim, ep, coins, walls, genomes, fstate, istate, n, "
+                 "n_steps, queue, static_cast<hipStream_t>(stream)); }\n")
     newest = max(p.stat().st_mtime for p in HEADERS + [Path(__file__)])
     if lib.exists() and src.exists() and src.read_text() == text and lib.stat().st_mtime >= newest:
         return lib

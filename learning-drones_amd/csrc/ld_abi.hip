@@ -15,6 +15,8 @@
 
 int ld_resident_dispatch(const ld_sim_params*, const ld_episode_params*, const ld_mlp_spec*, const double*, const double*,
                          const float*, float*, int32_t*, int64_t, int32_t, int32_t*, hipStream_t);   // ld_resident.hip
+bool ld_resident_has_f32(const ld_mlp_spec*);
+bool ld_resident_has_f64(const ld_mlp_spec*);
 int ld_resident_dispatch_f64(const ld_sim_params*, const ld_episode_params*, const ld_mlp_spec*, const double*, const double*,
                              const double*, double*, int32_t*, int64_t, int32_t, int32_t*, hipStream_t);
 
@@ -33,6 +35,7 @@ struct Specialisation {
     ld_mlp_spec spec;
     ld_fly_steps_f32_fn fly_steps;
     ld_mlp_forward_f32_fn mlp_forward;
+    ld_fly_resident_f32_fn fly_resident;               // may be NULL
 };
 constexpr int kMaxSpecialisations = 64;
 Specialisation g_specialisations[kMaxSpecialisations];
@@ -359,6 +362,18 @@ int pid_impl(const ld_sim_params* sim, const Real* gains, const double* coins, i
     return check_launch("pid_episode_kernel");
 }
 
+int resident_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec, const double* coins,
+                 const double* walls, const float* genomes, float* fstate, int32_t* istate, int64_t n, int32_t n_steps,
+                 int32_t* queue, void* stream)
+{
+    const int rc = ld_resident_dispatch(sim, ep, spec, coins, walls, genomes, fstate, istate, n, n_steps, queue,
+                                        static_cast<hipStream_t>(stream));
+    if (rc != LD_ERR_SPEC) return rc;
+    const Specialisation* s = find_specialisation(*spec);             // a spec specialised at run time
+    return s && s->fly_resident ? s->fly_resident(sim, ep, coins, walls, genomes, fstate, istate, n, n_steps, queue, stream)
+                                : LD_ERR_SPEC;
+}
+
 }  // namespace
 
 extern "C" {
@@ -371,8 +386,7 @@ int ld_fly_steps_resident_f32(const ld_sim_params* sim, const ld_episode_params*
     const int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
     if (rc || n == 0 || n_steps == 0) return rc;
     if (!queue) return LD_ERR_NULL;
-    return ld_resident_dispatch(sim, ep, spec, coins, walls, genomes, fstate, istate, n, n_steps, queue,
-                                static_cast<hipStream_t>(stream));
+    return resident_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, n_steps, queue, stream);
 }
 
 int ld_fly_rollout_resident_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,
@@ -390,8 +404,7 @@ int ld_fly_rollout_resident_f32(const ld_sim_params* sim, const ld_episode_param
     if (!genomes || !fstate || !istate || !queue) return LD_ERR_NULL;
     if (!aligned16(genomes)) return LD_ERR_ALIGN;
     if (timesteps > 0) {
-        rc = ld_resident_dispatch(sim, ep, spec, coins, walls, genomes, fstate, istate, n, timesteps, queue,
-                                  static_cast<hipStream_t>(stream));
+        rc = resident_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, timesteps, queue, stream);
     }
     if (rc) return rc;
     return finalize_impl<float>(ep, coins, fstate, istate, records, nullptr, n, stream);
@@ -453,7 +466,8 @@ int ld_version(void) { return LD_ABI_VERSION; }
 
 int ld_debug_force_generic(int on) { return g_force_generic.exchange(on ? 1 : 0); }
 
-int ld_register_specialisation_f32(const ld_mlp_spec* spec, ld_fly_steps_f32_fn fly_steps, ld_mlp_forward_f32_fn mlp_forward)
+int ld_register_specialisation_f32(const ld_mlp_spec* spec, ld_fly_steps_f32_fn fly_steps, ld_mlp_forward_f32_fn mlp_forward,
+                                   ld_fly_resident_f32_fn fly_resident)
 {
     const int rc = check_spec(spec);
     if (rc) return rc;
@@ -464,7 +478,7 @@ int ld_register_specialisation_f32(const ld_mlp_spec* spec, ld_fly_steps_f32_fn 
     for (int i = 0; i < count; ++i)
         if (same_spec(g_specialisations[i].spec, *spec)) return LD_ERR_SIZE;
     if (count >= kMaxSpecialisations) return LD_ERR_SIZE;
-    g_specialisations[count] = Specialisation{*spec, fly_steps, mlp_forward};
+    g_specialisations[count] = Specialisation{*spec, fly_steps, mlp_forward, fly_resident};
     g_n_specialisations.store(count + 1, std::memory_order_release);
     return LD_OK;
 }
@@ -474,6 +488,22 @@ int ld_has_specialisation_f32(const ld_mlp_spec* spec)
     const int rc = check_spec(spec);
     if (rc) return rc;
     return has_unrolled(*spec) ? 1 : 0;
+}
+
+int ld_has_resident_f32(const ld_mlp_spec* spec)
+{
+    const int rc = check_spec(spec);
+    if (rc) return rc;
+    if (ld_resident_has_f32(spec)) return 1;
+    const Specialisation* s = find_specialisation(*spec);
+    return s && s->fly_resident ? 1 : 0;
+}
+
+int ld_has_resident_f64(const ld_mlp_spec* spec)
+{
+    const int rc = check_spec(spec);
+    if (rc) return rc;
+    return ld_resident_has_f64(spec) ? 1 : 0;
 }
 
 int ld_accelerations_f32(const ld_sim_params* sim, const float* angle, const float* thrust, float* lin_acc, float* rot_acc,

@@ -78,3 +78,19 @@ int ld_resident_dispatch_f64(const ld_sim_params* sim, const ld_episode_params* 
 #undef X
     return LD_ERR_SPEC;
 }
+
+bool ld_resident_has_f32(const ld_mlp_spec* spec)
+{
+#define X(L, ...) if (resident_matches<__VA_ARGS__>(*spec)) return true;
+    LD_FOR_EACH_RESIDENT(X)
+#undef X
+    return false;
+}
+
+bool ld_resident_has_f64(const ld_mlp_spec* spec)
+{
+#define X(L, ...) if (resident_matches<__VA_ARGS__>(*spec)) return true;
+    LD_FOR_EACH_RESIDENT_F64(X)
+#undef X
+    return false;
+}

@@ -242,8 +242,9 @@ class Population:
     RESIDENT_SPECS_F64 = ((8, 10), (10, 10), (16, 16), (32, 32), (16,), (32,), (64,), (8, 8), (24, 24))
 
     def has_resident_engine(self) -> bool:
-        specs = self.RESIDENT_SPECS if self.precision == "f32" else self.RESIDENT_SPECS_F64
-        return self.spec.hidden_widths in specs
+        """Built in (RESIDENT_SPECS / RESIDENT_SPECS_F64) or, float32, compiled by specialise()."""
+        fn = _native.lib().ld_has_resident_f32 if self.precision == "f32" else _native.lib().ld_has_resident_f64
+        return fn(C.byref(self.spec)) == 1
 
     def fly(self, timesteps: int = 2500, engine: str = "step", steps_per_launch: Optional[int] = None,
             waves_per_block: int = 0):

@@ -465,5 +465,9 @@ def test_runtime_specialised_spec_equals_generic_kernels(Population, torch, gene
         pop.reset()
         pop.fly(T, steps_per_launch=k, waves_per_block=waves)
         assert torch.equal(pop.records, ref.records), (waves, k)
+    assert pop.has_resident_engine()                                     # the specialisation brings the resident engine too
+    pop.reset()
+    pop.fly(T, engine="resident")
+    assert torch.equal(pop.records, ref.records) and torch.equal(pop.fstate, ref.fstate)
     crashed = (ref.istate[2] & 1).bool()
     assert crashed.any() and not crashed.all()

@@ -211,10 +211,14 @@ def test_runtime_specialisation_builds_and_registers(lib):
     assert so_path.exists() and ld_build.build_specialisation((13, 7)) == so_path            # cached
     so = C.CDLL(str(so_path))
     fly, mlp = C.cast(so.ld_spec_fly_steps_f32, C.c_void_p), C.cast(so.ld_spec_mlp_forward_f32, C.c_void_p)
-    assert lib.ld_register_specialisation_f32(C.byref(spec), None, mlp) == -1
-    assert lib.ld_register_specialisation_f32(C.byref(MlpSpec.from_hidden((32, 32))), fly, mlp) == -3      # ships unrolled
+    res = C.cast(so.ld_spec_fly_resident_f32, C.c_void_p)
+    assert lib.ld_register_specialisation_f32(C.byref(spec), None, mlp, res) == -1
+    assert lib.ld_register_specialisation_f32(C.byref(MlpSpec.from_hidden((32, 32))), fly, mlp, res) == -3      # ships unrolled
+    assert lib.ld_has_resident_f32(C.byref(spec)) == 0 and lib.ld_has_resident_f32(C.byref(MlpSpec.from_hidden((32, 32)))) == 1
+    assert lib.ld_has_resident_f64(C.byref(MlpSpec.from_hidden((64, 64, 64)))) == 0 and lib.ld_has_resident_f64(C.byref(MlpSpec.from_hidden((10, 10)))) == 1
     assert _native.specialise((13, 7)) is True and lib.ld_has_specialisation_f32(C.byref(spec)) == 1
-    assert lib.ld_register_specialisation_f32(C.byref(spec), fly, mlp) == -3                                 # already there
+    assert lib.ld_register_specialisation_f32(C.byref(spec), fly, mlp, None) == -3                           # already there
+    assert lib.ld_has_resident_f32(C.byref(spec)) == 1                   # the specialisation brought a resident kernel
     assert _native.specialise((13, 7)) is True and _native.specialise((16, 16)) is True                       # no-ops
     k, w, m = C.c_int32(), C.c_int32(), C.c_int32()
     assert lib.ld_fly_rollout_geometry_f32(C.byref(spec), 8192, 2000, C.byref(k), C.byref(w), C.byref(m)) == 0

@@ -296,6 +296,7 @@ class DeviceEvolution:
         self.global_best_score = None if gb == -2**62 else gb
         self.elite = None if len(z["elite"]) == 0 else torch.as_tensor(z["elite"]).to(self.pop.local.device, self.pop.local.dtype)
         self.history = [tuple(int(v) for v in row) for row in z["history"]]
-        self.slot_of = None if len(z["slot_of"]) == 0 else torch.as_tensor(z["slot_of"]).to(self.pop.local.device)
+        slot_of = z["slot_of"] if "slot_of" in z else _np.zeros((0,), _np.int64)      # (absent in round-1 checkpoints)
+        self.slot_of = None if len(slot_of) == 0 else torch.as_tensor(slot_of).to(self.pop.local.device)
         self.pop.local.set_genomes(z["genes"])
         self.pop.local.reset()

@@ -109,6 +109,8 @@ def main():
                     "population, split over the ranks (BASELINE's 8-GPU target is quoted for a 65 536-drone population in all)")
     ap.add_argument("--steps-per-launch", type=int, default=0, help="timesteps per fused launch (0 = the library's choice)")
     ap.add_argument("--waves-per-block", type=int, default=0, help="wavefronts per 64-drone genome block (0 = the library's choice)")
+    ap.add_argument("--tile-drones", type=int, default=0, help="drones per tile of the rollout (0 = the library's choice: tiles of "
+                    "~120 MB of genes when the population's genes exceed the Infinity Cache; the --drones value = no tiling)")
     ap.add_argument("--specialise", action="store_true", help="compile the unrolled kernels for --hidden at first use if the "
                     "library does not ship them (learning_drones_amd.specialise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -165,8 +167,9 @@ def main():
         return float(t.item())
 
     def fly_kwargs():
-        if args.steps_per_launch or args.waves_per_block:
-            return dict(steps_per_launch=args.steps_per_launch or None, waves_per_block=args.waves_per_block)
+        if args.steps_per_launch or args.waves_per_block or args.tile_drones:
+            return dict(steps_per_launch=args.steps_per_launch or None, waves_per_block=args.waves_per_block,
+                        tile_drones=args.tile_drones or None)
         return {}
 
     def measure(n_local, steps, warmup):
@@ -178,11 +181,12 @@ def main():
         assert pop.local.n == n_local
         pop.local.set_genomes(make_genomes(torch, n_local, hidden, device, seed=rank))
         geo = pop.local.rollout_geometry(T)
-        if args.steps_per_launch:
-            geo["steps_per_launch"] = args.steps_per_launch
-            geo["launches"] = -(-T // args.steps_per_launch)
-        if args.waves_per_block:
-            geo["waves_per_block"] = args.waves_per_block
+        if args.steps_per_launch or args.waves_per_block or args.tile_drones:      # explicit geometry
+            k = args.steps_per_launch or geo["steps_per_launch"]
+            tile = min(args.tile_drones or geo["tile_drones"], n_local)
+            geo.update(steps_per_launch=k, tile_drones=tile, launches=-(-n_local // tile) * -(-T // k))
+            if args.waves_per_block:
+                geo["waves_per_block"] = args.waves_per_block
 
         def episode():
             pop.local.reset()
@@ -201,7 +205,8 @@ def main():
         fence()
         dt = max_over_ranks(time.perf_counter() - t0)
         launch_ms = ev0.elapsed_time(ev1) / (steps * geo["launches"]) if steps else float("nan")
-        bytes_per_launch = pop.local.bytes_per_launch(geo["steps_per_launch"])
+        # algorithmic bytes of ONE launch: a (full) tile's drones x (timesteps per launch x 4P + 200)
+        bytes_per_launch = pop.local.bytes_per_launch(geo["steps_per_launch"], geo["tile_drones"])
         achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "kernel": ("fly_split_kernel<float, L=%d, %s>" % (geo["waves_per_block"], "-".join(map(str, hidden)))
@@ -209,9 +214,14 @@ def main():
                            else "fly_step_kernel<float, GenericNet> (run-time layer spec)"),
                 "bytes_per_launch": bytes_per_launch, "launch_us": launch_ms * 1e3,
                 "timesteps_per_launch": geo["steps_per_launch"], "wavefronts_per_block": geo["waves_per_block"],
-                "launches_per_episode": geo["launches"],
-                "bytes_model": "n * (timesteps_per_launch * 4P + 200): genes once per timestep, the 25 state words read and "
-                               "written once per launch (they stay in registers in between); 4P + 200 per drone-step at 1"}
+                "launches_per_episode": geo["launches"], "drones_per_launch": geo["tile_drones"],
+                "tiles": -(-n_local // geo["tile_drones"]),
+                "tiling_note": "a population whose genes exceed the 256 MiB Infinity Cache is flown tile by tile (a tile's whole "
+                               "episode, then the next tile): the genes, re-streamed every timestep, then come from HBM once per "
+                               "episode and from the cache afterwards, so `achieved` (algorithmic bytes / time) can exceed the HBM "
+                               "peak; `traffic` is what the memory-side counters saw",
+                "bytes_model": "drones_per_launch * (timesteps_per_launch * 4P + 200): genes once per timestep, the 25 state words "
+                               "read and written once per launch (they stay in registers in between); 4P + 200 per drone-step at 1"}
         return pop, records, dt, roof
 
     n_total_strong = args.drones
@@ -309,7 +319,8 @@ def main():
             continue
         if (cfg["drones"] == n_local and tuple(cfg["hidden"]) == hidden and cfg["coins"] == args.coins
                 and cfg.get("timesteps_per_launch", 1) == roof["timesteps_per_launch"]
-                and cfg.get("wavefronts_per_block", 1) == roof["wavefronts_per_block"]):
+                and cfg.get("wavefronts_per_block", 1) == roof["wavefronts_per_block"]
+                and cfg.get("drones_per_launch", cfg["drones"]) == roof["drones_per_launch"]):
             roof["traffic"], roof["traffic_source"] = prof["hbm_traffic_bytes_per_launch"], f"profiles/{f.name}"
             if prof.get("launch_us_profiled"):
                 roof["launch_us_profiled"] = prof["launch_us_profiled"]
@@ -394,7 +405,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{config_name}: {n_local} drones/GPU x {T} timesteps, 15-{'-'.join(map(str, hidden))}-4 "
                                    f"controller per drone, {args.coins}-coin chain, crash penalty; step = one episode "
-                                   f"({roof['launches_per_episode']} fused launches of {roof['timesteps_per_launch']} timesteps + finalize"
+                                   f"({roof['launches_per_episode']} fused launches of {roof['timesteps_per_launch']} timesteps x "
+                                   f"{roof['drones_per_launch']} drones + finalize"
                                    + (" + RCCL all-gather of fitness records)" if world > 1 else ")"),
                        "population": n_total, "timesteps": T, "hidden": list(hidden), "coins": args.coins,
                        "parallelism": f"population sharded x{world}, no data-path collective inside the rollout"},

@@ -269,21 +269,27 @@ int ld_fly_rollout_f64(const ld_sim_params *sim, const ld_episode_params *ep, co
                        double *distance_f64, int64_t n, int32_t timesteps, void *stream);
 
 /* As ld_fly_rollout_f32 with the launch geometry explicit: `steps_per_launch` loop iterations per
- * launch (ld_fly_steps_f32; 1 = one launch per timestep, 0 = the library's choice, 16) and
- * `waves_per_block` as in ld_fly_steps_f32.  ld_fly_rollout_f32 is this with (0, 0) for the specs that
- * have an unrolled specialisation; LD_ERR_SPEC for the others. */
+ * launch (ld_fly_steps_f32; 1 = one launch per timestep, 0 = the library's choice, 16),
+ * `waves_per_block` as in ld_fly_steps_f32, and `tile_drones` (a multiple of 64; 0 = the library's
+ * choice, n = no tiling): the population is flown tile by tile, a tile's whole episode before the next
+ * tile starts, so that a tile's genes -- re-streamed every timestep -- come from HBM once per episode
+ * and from the 256 MiB Infinity Cache afterwards.  The library tiles only when the population's genes
+ * exceed the cache and at least 16 384 drones' genes fit in ~120 MB (config 3: four tiles of 16 384).
+ * Drones are independent, so results do not depend on the tiling.  ld_fly_rollout_f32 is this with
+ * (0, 0, 0) for the specs that have an unrolled specialisation; LD_ERR_SPEC for the others. */
 int ld_fly_rollout_steps_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
                              const double *coins, const double *walls, const float *genomes,
                              float *fstate, int32_t *istate, ld_fitness_record *records,
                              int64_t n, int32_t timesteps, int32_t steps_per_launch, int32_t waves_per_block,
-                             void *stream);
+                             int64_t tile_drones, void *stream);
 
-/* What ld_fly_rollout_f32 / ld_fly_rollout_steps_f32(..., 0, 0) will launch for this spec and shard size
+/* What ld_fly_rollout_f32 / ld_fly_rollout_steps_f32(..., 0, 0, 0) will launch for this spec and shard size
  * (for reporting: a benchmark states the geometry it measured): loop iterations per launch, wavefronts
- * per genome block, and the number of fused-step launches of a `timesteps`-step episode.  Specs without an
- * unrolled specialisation: 1, 1, timesteps. */
+ * per genome block, the number of fused-step launches of a `timesteps`-step episode, and the drones per
+ * tile (n when the rollout is not tiled).  Specs without an unrolled specialisation: 1, 1, timesteps, n. */
 int ld_fly_rollout_geometry_f32(const ld_mlp_spec *spec, int64_t n, int32_t timesteps,
-                                int32_t *steps_per_launch, int32_t *waves_per_block, int32_t *n_launches);
+                                int32_t *steps_per_launch, int32_t *waves_per_block, int32_t *n_launches,
+                                int64_t *tile_drones);
 
 /* fly(drone, timesteps) with the genome RESIDENT in registers for the whole episode (float32): ONE launch
  * runs all `timesteps` iterations; each drone owns L lanes of a wavefront that share its neurons, so the
@@ -328,9 +334,11 @@ int ld_fly_steps_resident_f32(const ld_sim_params *sim, const ld_episode_params 
  * fallback for everything that is not registered.  Returns LD_ERR_SIZE when the registry is full or the
  * spec already has an unrolled kernel.
  * ------------------------------------------------------------------------------------------- */
+/* drones [begin, end) of a population of n (begin a multiple of 64: the rollouts fly large populations in tiles) */
 typedef int (*ld_fly_steps_f32_fn)(const ld_sim_params *sim, const ld_episode_params *ep, const double *coins,
                                    const double *walls, const float *genomes, float *fstate, int32_t *istate,
-                                   int64_t n, int32_t n_steps, int32_t waves_per_block, void *stream);
+                                   int64_t n, int64_t begin, int64_t end, int32_t n_steps, int32_t waves_per_block,
+                                   void *stream);
 typedef int (*ld_mlp_forward_f32_fn)(const ld_mlp_spec *spec, const float *genomes, const float *inputs,
                                      float *outputs, int64_t n, void *stream);
 /* n_steps iterations of the genome-resident kernel, no finalize (what ld_fly_steps_resident_f32 runs). */

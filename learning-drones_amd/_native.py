@@ -97,7 +97,7 @@ def _declare(h: C.CDLL) -> None:
     h.ld_fly_rollout_resident_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]
     h.ld_fly_rollout_resident_f64.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]
     h.ld_fly_steps_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, i64, i32, i32, vp]
-    h.ld_fly_rollout_steps_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
+    h.ld_fly_rollout_steps_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i64, vp]
     h.ld_accelerations_f32.argtypes = [sim, vp, vp, vp, vp, i64, vp]
     h.ld_accelerations_f64.argtypes = [sim, vp, vp, vp, vp, i64, vp]
     h.ld_debug_force_generic.argtypes = [C.c_int]
@@ -107,7 +107,7 @@ def _declare(h: C.CDLL) -> None:
     h.ld_has_resident_f64.argtypes = [spec]
     h.ld_fly_steps_resident_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, i64, i32, vp, vp]
     pi32 = C.POINTER(C.c_int32)
-    h.ld_fly_rollout_geometry_f32.argtypes = [spec, i64, i32, pi32, pi32, pi32]
+    h.ld_fly_rollout_geometry_f32.argtypes = [spec, i64, i32, pi32, pi32, pi32, C.POINTER(C.c_int64)]
     ga = C.POINTER(GaParams)
     h.ld_ga_select.argtypes = [ga, spec, vp, i64, i64, i64, vp, vp, vp]
     h.ld_ga_breed_f32.argtypes = [ga, spec, vp, i64, i32, vp, vp, vp, i64, i64, vp, vp, vp]

@@ -122,10 +122,10 @@ def build_specialisation(hidden, verbose: bool = False) -> Path:
             f"#define LD_TAG jit_{tag}\n#define LD_WIDTHS {widths}\n#define LD_ONLY_F32\n"
             f'#include "{CSRC}/ld_unrolled.inc"\n#include "{CSRC}/ld_split.inc"\n#include "{CSRC}/ld_resident.hpp"\n'
             'extern "C" int ld_spec_fly_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, const double* coins, '
-            "const double* walls, const float* genomes, float* fstate, int32_t* istate, int64_t n, int32_t n_steps, "
-            "int32_t waves_per_block, void* stream)\n"
-            f"{{ return ld_u_split_f32_jit_{tag}(sim, ep, coins, walls, genomes, fstate, istate, n, n_steps, waves_per_block, "
-            "static_cast<hipStream_t>(stream)); }\n"
+            "const double* walls, const float* genomes, float* fstate, int32_t* istate, int64_t n, int64_t begin, int64_t end, "
+            "int32_t n_steps, int32_t waves_per_block, void* stream)\n"
+            f"{{ return ld_u_split_f32_jit_{tag}(sim, ep, coins, walls, genomes, fstate, istate, n, begin, end, n_steps, "
+            "waves_per_block, static_cast<hipStream_t>(stream)); }\n"
             'extern "C" int ld_spec_mlp_forward_f32(const ld_mlp_spec* spec, const float* genomes, const float* inputs, '
             "float* outputs, int64_t n, void* stream)\n"
             f"{{ return ld_u_mlp_f32_jit_{tag}(spec, genomes, inputs, outputs, n, static_cast<hipStream_t>(stream)); }}\n")

@@ -12,6 +12,12 @@
 #ifndef LD_STEPS_PER_LAUNCH
 #define LD_STEPS_PER_LAUNCH 16
 #endif
+#ifndef LD_TILE_BYTES
+#define LD_TILE_BYTES (120 << 20)          // genes per tile of a tiled rollout (the Infinity Cache holds 256 MiB)
+#endif
+#ifndef LD_TILE_WHOLE_BELOW
+#define LD_TILE_WHOLE_BELOW (200 << 20)    // populations whose genes fit in the cache as they are are not tiled
+#endif
 
 int ld_resident_dispatch(const ld_sim_params*, const ld_episode_params*, const ld_mlp_spec*, const double*, const double*,
                          const float*, float*, int32_t*, int64_t, int32_t, int32_t*, hipStream_t);   // ld_resident.hip
@@ -122,31 +128,32 @@ int dispatch_mlp(const ld_mlp_spec* spec, const Real* genomes, const Real* input
 // Wavefronts per 64-drone genome block for the split kernel (ld_split.hpp), from the measured grid
 // (scripts/ab_grid.py, profiles/r02_split_grid.json): a launch of several timesteps wants about two
 // wavefronts per SIMD chip-wide (2 048), a launch of one timestep about one (1 024: its fixed latency chain
-// -- state load, rigid-body step, barriers -- grows with the wavefronts per block); the 64-wide nets stop at 4
-// (their L = 8 kernel has the registers for a 16-word ring only at two wavefronts per SIMD).
+// -- state load, rigid-body step, barriers -- grows with the wavefronts per block).  L = 8 (256 registers per
+// wavefront: a 16-word ring instead of 32) is taken only where L = 4 would leave SIMDs empty; the 64-wide nets
+// stop at 4.
 int auto_waves_per_block(const ld_mlp_spec* spec, int64_t n, int32_t n_steps)
 {
     const int64_t blocks = (n + 63) / 64;
     const int64_t target = n_steps > 1 ? 2048 : 1024;
-    const int cap = ld_mlp_words_per_drone(spec) > 512 ? 4 : 8;
     int waves = 1;
-    while (waves * 2 <= cap && blocks * waves * 2 <= target) waves *= 2;
+    while (waves * 2 <= 4 && blocks * waves * 2 <= target) waves *= 2;
+    if (waves == 4 && blocks * 4 < 1024 && ld_mlp_words_per_drone(spec) <= 512) waves = 8;
     return waves;
 }
 
-// n_steps loop iterations in one launch, float32, unrolled specs only (LD_ERR_SPEC otherwise).
+// Drones [begin, end) of a population of n (begin a multiple of 64).
 int dispatch_split_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec, const double* coins,
-                       const double* walls, const float* genomes, float* fstate, int32_t* istate, int64_t n,
-                       int32_t n_steps, int32_t waves, hipStream_t stream)
+                       const double* walls, const float* genomes, float* fstate, int32_t* istate, int64_t n, int64_t begin,
+                       int64_t end, int32_t n_steps, int32_t waves, hipStream_t stream)
 {
-    if (waves == 0) waves = auto_waves_per_block(spec, n, n_steps);
+    if (waves == 0) waves = auto_waves_per_block(spec, end - begin, n_steps);
 #define X(TAG, ...)                                                                                          \
     if (spec_is<__VA_ARGS__>(*spec))                                                                         \
-        return ld_u_split_f32_##TAG(sim, ep, coins, walls, genomes, fstate, istate, n, n_steps, waves, stream);
+        return ld_u_split_f32_##TAG(sim, ep, coins, walls, genomes, fstate, istate, n, begin, end, n_steps, waves, stream);
     LD_FOR_EACH_UNROLLED(X)
 #undef X
     if (const Specialisation* s = find_specialisation(*spec))
-        return s->fly_steps(sim, ep, coins, walls, genomes, fstate, istate, n, n_steps, waves, stream);
+        return s->fly_steps(sim, ep, coins, walls, genomes, fstate, istate, n, begin, end, n_steps, waves, stream);
     return LD_ERR_SPEC;
 }
 
@@ -192,7 +199,7 @@ int fly_step_impl(const ld_sim_params* sim, const ld_episode_params* ep, const l
     if (rc || n == 0) return rc;                    // an empty population is a no-op
     if constexpr (sizeof(Real) == 4) {
         if (has_unrolled(*spec))
-            return dispatch_split_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, 1, 0,
+            return dispatch_split_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, 0, n, 1, 0,
                                       static_cast<hipStream_t>(stream));
     }
     return dispatch_fly_step<Real, Faithful>(sim, ep, spec, coins, walls, genomes, fstate, istate, n,
@@ -221,22 +228,42 @@ int finalize_impl(const ld_episode_params* ep, const double* coins, const Real* 
 // the launch count of a 2 000-step episode at 125 and the stream responsive.
 int auto_steps_per_launch() { return LD_STEPS_PER_LAUNCH; }
 
+// Drones per tile of a rollout.  A launch re-streams its drones' genes every timestep; when they exceed the
+// 256 MiB Infinity Cache (config 3: 446 MB) every timestep comes from HBM.  Flown tile by tile -- a tile's
+// whole episode before the next tile starts -- with tiles of about 112 MB of genes, the genes come from HBM
+// once per episode and from the Infinity Cache afterwards: 16 384-drone tiles of a 32-32 population run
+// 13.0-13.6 us per timestep each (8.4-8.8 TB/s algorithmic) against 62.3 us for all 65 536 at once.  A
+// tile must still fill the chip, so only nets small enough for >= 16 384 drones per tile are tiled.
+int64_t auto_tile_drones(const ld_mlp_spec* spec, int64_t n)
+{
+    const int64_t bytes_per_drone = 4 * ld_mlp_param_count(spec);
+    if (n * bytes_per_drone <= (int64_t)LD_TILE_WHOLE_BELOW) return n;            // fits as it is
+    int64_t tile = 1 << 14;
+    while (tile * 2 * bytes_per_drone <= (int64_t)LD_TILE_BYTES) tile *= 2;
+    if (tile * bytes_per_drone > (int64_t)LD_TILE_BYTES) return n;                 // not even 16 384 drones fit: no tiling
+    return tile < n ? tile : n;
+}
+
 int rollout_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec, const double* coins,
                       const double* walls, const float* genomes, float* fstate, int32_t* istate,
                       ld_fitness_record* records, int64_t n, int32_t timesteps, int32_t steps_per_launch, int32_t waves,
-                      void* stream)
+                      int64_t tile_drones, void* stream)
 {
-    if (timesteps < 0 || steps_per_launch < 0) return LD_ERR_SIZE;
+    if (timesteps < 0 || steps_per_launch < 0 || tile_drones < 0 || (tile_drones % 64) != 0) return LD_ERR_SIZE;
     if (waves != 0 && waves != 1 && waves != 2 && waves != 4 && waves != 8) return LD_ERR_SIZE;
     int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
     if (rc || n == 0) return rc;
     if (!has_unrolled(*spec)) return LD_ERR_SPEC;
     if (steps_per_launch == 0) steps_per_launch = auto_steps_per_launch();
-    for (int32_t t = 0; t < timesteps; t += steps_per_launch) {
-        const int32_t k = timesteps - t < steps_per_launch ? timesteps - t : steps_per_launch;
-        rc = dispatch_split_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, k, waves,
-                                static_cast<hipStream_t>(stream));
-        if (rc) return rc;
+    if (tile_drones == 0) tile_drones = auto_tile_drones(spec, n);
+    for (int64_t begin = 0; begin < n; begin += tile_drones) {              // a tile's whole episode, then the next tile
+        const int64_t end = begin + tile_drones < n ? begin + tile_drones : n;
+        for (int32_t t = 0; t < timesteps; t += steps_per_launch) {
+            const int32_t k = timesteps - t < steps_per_launch ? timesteps - t : steps_per_launch;
+            rc = dispatch_split_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, begin, end, k, waves,
+                                    static_cast<hipStream_t>(stream));
+            if (rc) return rc;
+        }
     }
     return finalize_impl<float>(ep, coins, fstate, istate, records, nullptr, n, stream);
 }
@@ -249,7 +276,7 @@ int rollout_impl(const ld_sim_params* sim, const ld_episode_params* ep, const ld
     if (timesteps < 0) return LD_ERR_SIZE;
     if constexpr (sizeof(Real) == 4) {
         if (spec && check_spec(spec) == LD_OK && has_unrolled(*spec))
-            return rollout_steps_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, records, n, timesteps, 0, 0, stream);
+            return rollout_steps_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, records, n, timesteps, 0, 0, 0, stream);
     }
     for (int32_t t = 0; t < timesteps; ++t) {
         const int rc = fly_step_impl<Real, Faithful>(sim, ep, spec, coins, walls, genomes, fstate, istate, n, stream);
@@ -523,31 +550,33 @@ int ld_fly_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, cons
     const int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
     if (rc || n == 0 || n_steps == 0) return rc;
     if (!has_unrolled(*spec)) return LD_ERR_SPEC;
-    return dispatch_split_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, n_steps, waves_per_block,
+    return dispatch_split_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, 0, n, n_steps, waves_per_block,
                               static_cast<hipStream_t>(stream));
 }
 
 int ld_fly_rollout_geometry_f32(const ld_mlp_spec* spec, int64_t n, int32_t timesteps, int32_t* steps_per_launch,
-                                int32_t* waves_per_block, int32_t* n_launches)
+                                int32_t* waves_per_block, int32_t* n_launches, int64_t* tile_drones)
 {
     const int rc = check_spec(spec);
     if (rc) return rc;
     if (n < 0 || timesteps < 0) return LD_ERR_SIZE;
-    if (!steps_per_launch || !waves_per_block || !n_launches) return LD_ERR_NULL;
+    if (!steps_per_launch || !waves_per_block || !n_launches || !tile_drones) return LD_ERR_NULL;
     const bool split = has_unrolled(*spec);
     *steps_per_launch = split ? auto_steps_per_launch() : 1;
-    *waves_per_block = split ? auto_waves_per_block(spec, n, *steps_per_launch) : 1;
-    *n_launches = (timesteps + *steps_per_launch - 1) / *steps_per_launch;
+    *tile_drones = split && n > 0 ? auto_tile_drones(spec, n) : n;
+    *waves_per_block = split ? auto_waves_per_block(spec, *tile_drones, *steps_per_launch) : 1;
+    const int64_t tiles = *tile_drones > 0 ? (n + *tile_drones - 1) / *tile_drones : 1;
+    *n_launches = (int32_t)(tiles * ((timesteps + *steps_per_launch - 1) / *steps_per_launch));
     return LD_OK;
 }
 
 int ld_fly_rollout_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,
                              const double* coins, const double* walls, const float* genomes, float* fstate,
                              int32_t* istate, ld_fitness_record* records, int64_t n, int32_t timesteps,
-                             int32_t steps_per_launch, int32_t waves_per_block, void* stream)
+                             int32_t steps_per_launch, int32_t waves_per_block, int64_t tile_drones, void* stream)
 {
     return rollout_steps_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, records, n, timesteps, steps_per_launch,
-                             waves_per_block, stream);
+                             waves_per_block, tile_drones, stream);
 }
 
 const char* ld_strerror(int status)

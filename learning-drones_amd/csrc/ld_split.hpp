@@ -125,8 +125,11 @@ template <typename Real, bool Faithful, int L, int... H>
 __global__ void __launch_bounds__(64 * L)
 fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restrict__ coins,
                  const double* __restrict__ walls, const GeneWord<Real>* __restrict__ genomes,
-                 Real* __restrict__ fstate, int32_t* __restrict__ istate, const int64_t n, const int32_t n_steps)
+                 Real* __restrict__ fstate, int32_t* __restrict__ istate, const int64_t n, const int64_t begin,
+                 const int64_t end, const int32_t n_steps)
 {
+    // The launch covers drones [begin, end) of a population of n (begin a multiple of 64): a rollout may fly a
+    // large population tile by tile so that a tile's genes stay in the Infinity Cache between timesteps.
     using Plan = SplitPlan<L, H...>;
     using Shape = typename Plan::Shape;
     constexpr int NL = Shape::n_layers;
@@ -144,9 +147,9 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
 
     const int lane = threadIdx.x & 63;
     const int wave = L == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t gid = (int64_t)blockIdx.x * 64 + lane;
-    const bool valid = gid < n;
-    const int64_t i = valid ? gid : n - 1;                    // tail lanes read drone n-1, store nothing
+    const int64_t gid = begin + (int64_t)blockIdx.x * 64 + lane;
+    const bool valid = gid < end;
+    const int64_t i = valid ? gid : end - 1;                  // tail lanes read the last drone, store nothing
 
     // the drone's own words first, the gene ring behind them (vmcnt counts in issue order: the physics
     // can start as soon as the state is in, with the ring still in flight)
@@ -304,11 +307,12 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
 
 template <typename Real, bool Faithful, int L, int... H>
 int launch_fly_split(const ld_sim_params* sim, const ld_episode_params* ep, const double* coins, const double* walls,
-                     const Real* genomes, Real* fstate, int32_t* istate, int64_t n, int32_t n_steps, hipStream_t stream)
+                     const Real* genomes, Real* fstate, int32_t* istate, int64_t n, int64_t begin, int64_t end,
+                     int32_t n_steps, hipStream_t stream)
 {
-    hipLaunchKernelGGL((fly_split_kernel<Real, Faithful, L, H...>), dim3(blocks_for(n, 64)), dim3(64 * L), 0, stream,
+    hipLaunchKernelGGL((fly_split_kernel<Real, Faithful, L, H...>), dim3(blocks_for(end - begin, 64)), dim3(64 * L), 0, stream,
                        make_sim<Real>(*sim), make_ep<Real>(*ep), coins, walls,
-                       reinterpret_cast<const GeneWord<Real>*>(genomes), fstate, istate, n, n_steps);
+                       reinterpret_cast<const GeneWord<Real>*>(genomes), fstate, istate, n, begin, end, n_steps);
     return check_launch("fly_split_kernel");
 }
 
@@ -317,5 +321,5 @@ int launch_fly_split(const ld_sim_params* sim, const ld_episode_params* ep, cons
 // One function per unrolled spec (ld_split_<tag>.hip): dispatch on the wavefronts per block.
 #define LD_DECLARE_SPLIT(TAG, ...)                                                                                \
     int ld_u_split_f32_##TAG(const ld_sim_params*, const ld_episode_params*, const double*, const double*,        \
-                             const float*, float*, int32_t*, int64_t, int32_t, int32_t, hipStream_t);
+                             const float*, float*, int32_t*, int64_t, int64_t, int64_t, int32_t, int32_t, hipStream_t);
 LD_FOR_EACH_UNROLLED(LD_DECLARE_SPLIT)

@@ -247,7 +247,7 @@ class Population:
         return fn(C.byref(self.spec)) == 1
 
     def fly(self, timesteps: int = 2500, engine: str = "step", steps_per_launch: Optional[int] = None,
-            waves_per_block: int = 0):
+            waves_per_block: int = 0, tile_drones: Optional[int] = None):
         """fly(drone, timesteps) for every drone, enqueued from C on the current stream.  Returns the
         device tensor of result records ([n, 4] int32 view of ld_fitness_record); see results().
 
@@ -255,7 +255,10 @@ class Population:
         default (float32, unrolled specs) a launch advances the population 16 timesteps with the drone
         state in registers in between, and a genome block's 64 drones get as many wavefronts as fill the
         chip; steps_per_launch / waves_per_block make that geometry explicit (ld_fly_rollout_steps_f32;
-        steps_per_launch=1 is one launch per timestep).  Results do not depend on the geometry.
+        steps_per_launch=1 is one launch per timestep).  A population whose genes exceed the 256 MiB Infinity
+        Cache is flown tile by tile (a tile's whole episode, then the next tile), so that the re-streamed genes
+        come from the cache after a tile's first timestep (tile_drones: a multiple of 64; None = the library's
+        choice, self.n = no tiling).  Results do not depend on the geometry.
         engine="resident" (specs RESIDENT_SPECS in float32, RESIDENT_SPECS_F64 in float64): one launch for the whole episode with the genome
         held in registers and drones handed to lane groups from a work queue (ld_fly_rollout_resident_f32);
         bit-identical results, 3-6x faster, and a population in which most drones crash early costs about
@@ -280,10 +283,10 @@ class Population:
             return self.records
         if engine != "step":
             raise ValueError("engine must be 'step' or 'resident'")
-        if steps_per_launch is not None or waves_per_block:
+        if steps_per_launch is not None or waves_per_block or tile_drones is not None:
             if self.precision != "f32":
-                raise ValueError("steps_per_launch / waves_per_block are float32 options")
-            args += [self.n, int(timesteps), int(steps_per_launch or 0), int(waves_per_block), self._stream()]
+                raise ValueError("steps_per_launch / waves_per_block / tile_drones are float32 options")
+            args += [self.n, int(timesteps), int(steps_per_launch or 0), int(waves_per_block), int(tile_drones or 0), self._stream()]
             _native.check(_native.lib().ld_fly_rollout_steps_f32(*args), "ld_fly_rollout_steps_f32")
             self._finalized = True
             return self.records
@@ -297,11 +300,12 @@ class Population:
     def rollout_geometry(self, timesteps: int) -> dict:
         """What fly(timesteps) (step engine, default geometry) launches: loop iterations per launch,
         wavefronts per genome block, fused-step launches per episode (ld_fly_rollout_geometry_f32)."""
-        k, w, m = C.c_int32(1), C.c_int32(1), C.c_int32(int(timesteps))
+        k, w, m, tile = C.c_int32(1), C.c_int32(1), C.c_int32(int(timesteps)), C.c_int64(self.n)
         if self.precision == "f32":
             _native.check(_native.lib().ld_fly_rollout_geometry_f32(C.byref(self.spec), self.n, int(timesteps), C.byref(k),
-                                                                    C.byref(w), C.byref(m)), "ld_fly_rollout_geometry_f32")
-        return {"steps_per_launch": k.value, "waves_per_block": w.value, "launches": m.value}
+                                                                    C.byref(w), C.byref(m), C.byref(tile)),
+                          "ld_fly_rollout_geometry_f32")
+        return {"steps_per_launch": k.value, "waves_per_block": w.value, "launches": m.value, "tile_drones": tile.value}
 
     def results(self) -> np.ndarray:
         """Host copy of the result records as a structured array with the extra convenience fields
@@ -474,8 +478,10 @@ class Population:
         word = 4 if self.precision == "f32" else 8
         return word * (self.P + 2 * F_COUNT) + 4 * 2 * I_COUNT
 
-    def bytes_per_launch(self, steps_per_launch: int = 1) -> int:
-        """Algorithmic bytes of one fused launch of `steps_per_launch` timesteps: the genes once per
-        timestep, the state read and written once per LAUNCH (it stays in registers in between)."""
+    def bytes_per_launch(self, steps_per_launch: int = 1, drones: Optional[int] = None) -> int:
+        """Algorithmic bytes of one fused launch of `steps_per_launch` timesteps over `drones` drones (a tile;
+        default: the whole population): the genes once per timestep, the state read and written once per
+        LAUNCH (it stays in registers in between)."""
         word = 4 if self.precision == "f32" else 8
-        return self.n * (steps_per_launch * word * self.P + word * 2 * F_COUNT + 4 * 2 * I_COUNT)
+        drones = self.n if drones is None else int(drones)
+        return drones * (steps_per_launch * word * self.P + word * 2 * F_COUNT + 4 * 2 * I_COUNT)

@@ -33,7 +33,8 @@ if a.bench:
     r = bench["roofline"]
     doc["config"] = {"drones": bench["config"]["population"] // bench["n_gpus"], "hidden": bench["config"]["hidden"],
                      "coins": bench["config"]["coins"], "timesteps": bench["config"]["timesteps"],
-                     "timesteps_per_launch": r["timesteps_per_launch"], "wavefronts_per_block": r["wavefronts_per_block"]}
+                     "timesteps_per_launch": r["timesteps_per_launch"], "wavefronts_per_block": r["wavefronts_per_block"],
+                     "drones_per_launch": r.get("drones_per_launch", bench["config"]["population"] // bench["n_gpus"])}
     doc["bench_line_of_the_traced_run"] = {"launch_us_from_hip_events": r["launch_us"], "achieved_gbs": r["achieved"],
                                            "frac": r["frac"], "value": bench["value"], "ms_per_step": bench["ms_per_step"]}
     doc["algorithmic_bytes_per_launch"] = r["bytes_per_launch"]

@@ -482,6 +482,10 @@ def test_split_waves_and_multistep_are_bit_identical(Population, torch, generic_
     pop = fresh()
     pop.fly(T, steps_per_launch=16, waves_per_block=4)
     assert torch.equal(pop.records, ref.records)
+    for tile in (64, 128, 192):                                   # tiled rollouts: whole tiles, and a ragged last one
+        pop = fresh()
+        pop.fly(T, tile_drones=tile)
+        assert torch.equal(pop.records, ref.records) and torch.equal(pop.fstate, ref.fstate), tile
 
 
 def test_full_size_config5_shard(Population, torch):

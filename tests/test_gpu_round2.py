@@ -243,7 +243,8 @@ def _replicated(hidden, m, n, seed):
 
 def test_full_size_config4_shard(Population, torch):
     """One GPU's share of BASELINE config 4: 32 768 drones x 4 000 steps, 15-32-32-4, 3-coin chain (the
-    launch geometry this shard gets: 4 wavefronts per block, 16 timesteps per launch).  Size-independent
+    launch geometry this shard gets: two tiles of 16 384 drones, 4 wavefronts per block, 16 timesteps per
+    launch).  Size-independent
     properties: genomes replicated from a 256-drone population under a random permutation give the
     permuted small-population results bit for bit; a re-run is bit-identical; one launch per timestep
     and the resident engine give the same records."""
@@ -257,13 +258,13 @@ def test_full_size_config4_shard(Population, torch):
     pop = Population(n, hidden, coins=coins)
     pop.set_genomes(torch.as_tensor(genes_m, dtype=torch.float32, device="cuda")[torch.as_tensor(src, device="cuda")])
     geo = pop.rollout_geometry(T)
-    assert geo == {"steps_per_launch": 16, "waves_per_block": 4, "launches": 250}
+    assert geo == {"steps_per_launch": 16, "waves_per_block": 4, "launches": 500, "tile_drones": 16384}
     pop.fly(T)
     got = pop.results()
     for f in ("reward", "flight_time", "coins", "crashed", "distance_to_coin"):
         assert np.array_equal(got[f], want[f][src]), f
     rec = pop.records.clone()
-    for kw in (dict(steps_per_launch=1), dict(engine="resident"), {}):
+    for kw in (dict(steps_per_launch=1), dict(tile_drones=n), dict(tile_drones=4096 + 64, waves_per_block=2), dict(engine="resident"), {}):
         pop.reset()
         pop.fly(T, **kw)
         assert torch.equal(pop.records, rec), kw

@@ -185,8 +185,8 @@ def main():
             k = args.steps_per_launch or geo["steps_per_launch"]
             tile = min(args.tile_drones or geo["tile_drones"], n_local)
             geo.update(steps_per_launch=k, tile_drones=tile, launches=-(-n_local // tile) * -(-T // k))
-            if args.waves_per_block:
-                geo["waves_per_block"] = args.waves_per_block
+            # the wavefronts per block the library picks for launches of `tile` drones (or the explicit value)
+            geo["waves_per_block"] = args.waves_per_block or pop.local.auto_waves_per_block(tile, k)
 
         def episode():
             pop.local.reset()

@@ -291,6 +291,10 @@ int ld_fly_rollout_geometry_f32(const ld_mlp_spec *spec, int64_t n, int32_t time
                                 int32_t *steps_per_launch, int32_t *waves_per_block, int32_t *n_launches,
                                 int64_t *tile_drones);
 
+/* The wavefronts per genome block ld_fly_steps_f32 takes for waves_per_block = 0 on a launch of n drones and
+ * n_steps timesteps (1 for specs without an unrolled specialisation), or a negative ld_status. */
+int ld_fly_steps_auto_waves_f32(const ld_mlp_spec *spec, int64_t n, int32_t n_steps);
+
 /* fly(drone, timesteps) with the genome RESIDENT in registers for the whole episode (float32): ONE launch
  * runs all `timesteps` iterations; each drone owns L lanes of a wavefront that share its neurons, so the
  * genes are read from HBM once per episode instead of once per step.  The wavefronts are persistent and

@@ -28,7 +28,7 @@ EXPORTS = (
     "ld_fly_rollout_resident_f32", "ld_debug_force_generic", "ld_accelerations_f32", "ld_accelerations_f64",
     "ld_fly_steps_f32", "ld_fly_rollout_steps_f32", "ld_fly_rollout_geometry_f32", "ld_fly_steps_resident_f32",
     "ld_fly_rollout_resident_f64", "ld_register_specialisation_f32", "ld_has_specialisation_f32",
-    "ld_has_resident_f32", "ld_has_resident_f64",
+    "ld_has_resident_f32", "ld_has_resident_f64", "ld_fly_steps_auto_waves_f32",
 )
 ABI_VERSION = 2
 
@@ -105,6 +105,7 @@ def _declare(h: C.CDLL) -> None:
     h.ld_has_specialisation_f32.argtypes = [spec]
     h.ld_has_resident_f32.argtypes = [spec]
     h.ld_has_resident_f64.argtypes = [spec]
+    h.ld_fly_steps_auto_waves_f32.argtypes = [spec, i64, i32]
     h.ld_fly_steps_resident_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, i64, i32, vp, vp]
     pi32 = C.POINTER(C.c_int32)
     h.ld_fly_rollout_geometry_f32.argtypes = [spec, i64, i32, pi32, pi32, pi32, C.POINTER(C.c_int64)]

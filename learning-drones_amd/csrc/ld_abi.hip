@@ -570,6 +570,14 @@ int ld_fly_rollout_geometry_f32(const ld_mlp_spec* spec, int64_t n, int32_t time
     return LD_OK;
 }
 
+int ld_fly_steps_auto_waves_f32(const ld_mlp_spec* spec, int64_t n, int32_t n_steps)
+{
+    const int rc = check_spec(spec);
+    if (rc) return rc;
+    if (n < 0 || n_steps < 0) return LD_ERR_SIZE;
+    return has_unrolled(*spec) ? auto_waves_per_block(spec, n, n_steps) : 1;
+}
+
 int ld_fly_rollout_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,
                              const double* coins, const double* walls, const float* genomes, float* fstate,
                              int32_t* istate, ld_fitness_record* records, int64_t n, int32_t timesteps,

@@ -307,6 +307,14 @@ class Population:
                           "ld_fly_rollout_geometry_f32")
         return {"steps_per_launch": k.value, "waves_per_block": w.value, "launches": m.value, "tile_drones": tile.value}
 
+    def auto_waves_per_block(self, drones: int, steps_per_launch: int) -> int:
+        """Wavefronts per genome block the library chooses (waves_per_block = 0) for a launch of `drones` drones
+        and `steps_per_launch` timesteps (ld_fly_steps_auto_waves_f32)."""
+        w = _native.lib().ld_fly_steps_auto_waves_f32(C.byref(self.spec), int(drones), int(steps_per_launch))
+        if w < 0:
+            _native.check(w, "ld_fly_steps_auto_waves_f32")
+        return w
+
     def results(self) -> np.ndarray:
         """Host copy of the result records as a structured array with the extra convenience fields
         of fly()/Drone: reward, flight_time, coins, crashed, distance_to_coin."""

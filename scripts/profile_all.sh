@@ -6,8 +6,9 @@ cd "$(dirname "$0")/.."
 out=$PWD/gpurun_out/prof
 mkdir -p $out
 export TMPDIR=/tmp
-scripts/profile_config.sh c3                                                       # BASELINE config 3 (headline)
-scripts/profile_config.sh c3_k1 --steps-per-launch 1 --waves-per-block 1           # the literal contract: one launch per timestep
+scripts/profile_config.sh c3                                                       # BASELINE config 3 (headline: four tiles of 16 384 drones)
+scripts/profile_config.sh c3_whole --tile-drones 65536                             # the same, all 65 536 drones per launch (HBM-bound)
+scripts/profile_config.sh c3_k1 --steps-per-launch 1 --waves-per-block 1 --tile-drones 65536   # the literal contract: one launch per timestep
 scripts/profile_config.sh shard8 --drones 8192                                     # 65 536-drone population over 8 GPUs: one shard
 scripts/profile_config.sh c4 --drones 32768 --timesteps 4000                       # config 4 shard
 scripts/profile_config.sh c2 --drones 1024 --hidden 16,16 --coins 1                # config 2

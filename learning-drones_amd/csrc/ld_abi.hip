@@ -234,8 +234,9 @@ int auto_steps_per_launch() { return LD_STEPS_PER_LAUNCH; }
 // once per episode and from the Infinity Cache afterwards: 16 384-drone tiles of a 32-32 population run
 // 13.0-13.6 us per timestep each (8.4-8.8 TB/s algorithmic) against 62.3 us for all 65 536 at once.  A
 // tile must still fill the chip, so only nets small enough for >= 16 384 drones per tile are tiled.
-int64_t auto_tile_drones(const ld_mlp_spec* spec, int64_t n)
+int64_t auto_tile_drones(const ld_mlp_spec* spec, int64_t n, int32_t steps_per_launch)
 {
+    if (steps_per_launch < 4) return n;      // one-timestep launches of 16 384 drones are latency-bound (18.4 vs 4 x 17 us whole)
     const int64_t bytes_per_drone = 4 * ld_mlp_param_count(spec);
     if (n * bytes_per_drone <= (int64_t)LD_TILE_WHOLE_BELOW) return n;            // fits as it is
     int64_t tile = 1 << 14;
@@ -255,7 +256,7 @@ int rollout_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, con
     if (rc || n == 0) return rc;
     if (!has_unrolled(*spec)) return LD_ERR_SPEC;
     if (steps_per_launch == 0) steps_per_launch = auto_steps_per_launch();
-    if (tile_drones == 0) tile_drones = auto_tile_drones(spec, n);
+    if (tile_drones == 0) tile_drones = auto_tile_drones(spec, n, steps_per_launch);
     for (int64_t begin = 0; begin < n; begin += tile_drones) {              // a tile's whole episode, then the next tile
         const int64_t end = begin + tile_drones < n ? begin + tile_drones : n;
         for (int32_t t = 0; t < timesteps; t += steps_per_launch) {
@@ -563,7 +564,7 @@ int ld_fly_rollout_geometry_f32(const ld_mlp_spec* spec, int64_t n, int32_t time
     if (!steps_per_launch || !waves_per_block || !n_launches || !tile_drones) return LD_ERR_NULL;
     const bool split = has_unrolled(*spec);
     *steps_per_launch = split ? auto_steps_per_launch() : 1;
-    *tile_drones = split && n > 0 ? auto_tile_drones(spec, n) : n;
+    *tile_drones = split && n > 0 ? auto_tile_drones(spec, n, *steps_per_launch) : n;
     *waves_per_block = split ? auto_waves_per_block(spec, *tile_drones, *steps_per_launch) : 1;
     const int64_t tiles = *tile_drones > 0 ? (n + *tile_drones - 1) / *tile_drones : 1;
     *n_launches = (int32_t)(tiles * ((timesteps + *steps_per_launch - 1) / *steps_per_launch));

@@ -7,8 +7,8 @@
 
 Workload (BASELINE config 3, the one the metric is quoted on): 65 536 drones per GPU x 2 000
 timesteps, 15-32-32-4 controller, 3-coin chain, crash penalty on, float32.  A "step" is one whole
-episode of the population = the fused-step launches of ld_fly_rollout_f32 (16 timesteps per launch, the
-drone state in registers in between: 125 launches) + the finalize launch (+ the RCCL all-gather of the
+episode of the population = the fused-step launches of ld_fly_rollout_f32 (four tiles of 16 384 drones, 64
+timesteps per launch with the drone state in registers in between: 128 launches) + the finalize launch (+ the RCCL all-gather of the
 16-byte fitness records when N > 1).  Population shards are independent, so the headline line is weak
 scaling: every rank owns 65 536 drones.  With N > 1 the same run ALSO times the strong-scaling case
 BASELINE's target describes (ONE 65 536-drone population split over the N GPUs) and reports it in the

@@ -269,7 +269,7 @@ int ld_fly_rollout_f64(const ld_sim_params *sim, const ld_episode_params *ep, co
                        double *distance_f64, int64_t n, int32_t timesteps, void *stream);
 
 /* As ld_fly_rollout_f32 with the launch geometry explicit: `steps_per_launch` loop iterations per
- * launch (ld_fly_steps_f32; 1 = one launch per timestep, 0 = the library's choice, 16),
+ * launch (ld_fly_steps_f32; 1 = one launch per timestep, 0 = the library's choice, 64),
  * `waves_per_block` as in ld_fly_steps_f32, and `tile_drones` (a multiple of 64; 0 = the library's
  * choice, n = no tiling): the population is flown tile by tile, a tile's whole episode before the next
  * tile starts, so that a tile's genes -- re-streamed every timestep -- come from HBM once per episode

@@ -10,7 +10,7 @@
 #include "ld_split.hpp"
 
 #ifndef LD_STEPS_PER_LAUNCH
-#define LD_STEPS_PER_LAUNCH 16
+#define LD_STEPS_PER_LAUNCH 64
 #endif
 #ifndef LD_TILE_BYTES
 #define LD_TILE_BYTES (120 << 20)          // genes per tile of a tiled rollout (the Infinity Cache holds 256 MiB)
@@ -223,9 +223,9 @@ int finalize_impl(const ld_episode_params* ep, const double* coins, const Real* 
 }
 
 // Loop iterations per launch of a rollout.  Every size gains from keeping the drone state in registers
-// across timesteps and dropping the per-step kernel boundary (65 536 x 32-32: 67.6 -> 62.9 us per step at
-// 16, 62.4 at 64; 8 192: 13.3 -> 9.3; 1 024 x 16-16: 7.7 -> 2.7), with little left beyond 16, which keeps
-// the launch count of a 2 000-step episode at 125 and the stream responsive.
+// across timesteps and dropping the per-step kernel boundary (65 536 x 32-32 in one launch: 67.6 us per
+// timestep at 1, 62.9 at 16, 62.4 at 64; 8 192: 13.3 / 9.3 / 9.0; 1 024 x 16-16: 7.7 / 2.7 / 2.5; config 3
+// in tiles: 113.3 ms per episode at 16, 109.9 at 64, 113.2 at 2 000), with nothing left beyond 64.
 int auto_steps_per_launch() { return LD_STEPS_PER_LAUNCH; }
 
 // Drones per tile of a rollout.  A launch re-streams its drones' genes every timestep; when they exceed the

@@ -252,7 +252,7 @@ class Population:
         device tensor of result records ([n, 4] int32 view of ld_fitness_record); see results().
 
         engine="step": the fused step kernel, genes streamed from memory every timestep, + finalize.  By
-        default (float32, unrolled specs) a launch advances the population 16 timesteps with the drone
+        default (float32, unrolled specs) a launch advances the population 64 timesteps with the drone
         state in registers in between, and a genome block's 64 drones get as many wavefronts as fill the
         chip; steps_per_launch / waves_per_block make that geometry explicit (ld_fly_rollout_steps_f32;
         steps_per_launch=1 is one launch per timestep).  A population whose genes exceed the 256 MiB Infinity

@@ -172,7 +172,7 @@ def main():
                         tile_drones=args.tile_drones or None)
         return {}
 
-    def measure(n_local, steps, warmup):
+    def measure(n_local, steps, warmup, force_tile=None):
         """`steps` timed episodes of a population of n_local drones per rank: barrier + synchronize on both
         sides, wall time = max over ranks; the fused launches' average duration from HIP events on the
         launch stream over the same region."""
@@ -181,16 +181,19 @@ def main():
         assert pop.local.n == n_local
         pop.local.set_genomes(make_genomes(torch, n_local, hidden, device, seed=rank))
         geo = pop.local.rollout_geometry(T)
-        if args.steps_per_launch or args.waves_per_block or args.tile_drones:      # explicit geometry
+        kwargs = fly_kwargs()
+        if force_tile:
+            kwargs = dict(steps_per_launch=args.steps_per_launch or None, waves_per_block=args.waves_per_block, tile_drones=force_tile)
+        if args.steps_per_launch or args.waves_per_block or args.tile_drones or force_tile:      # explicit geometry
             k = args.steps_per_launch or geo["steps_per_launch"]
-            tile = min(args.tile_drones or geo["tile_drones"], n_local)
+            tile = min(force_tile or args.tile_drones or geo["tile_drones"], n_local)
             geo.update(steps_per_launch=k, tile_drones=tile, launches=-(-n_local // tile) * -(-T // k))
             # the wavefronts per block the library picks for launches of `tile` drones (or the explicit value)
             geo["waves_per_block"] = args.waves_per_block or pop.local.auto_waves_per_block(tile, k)
 
         def episode():
             pop.local.reset()
-            return pop.fly(T, **fly_kwargs())          # fused launches + finalize (+ all-gather of records)
+            return pop.fly(T, **kwargs)                # fused launches + finalize (+ all-gather of records)
 
         for _ in range(warmup):
             episode()
@@ -205,8 +208,12 @@ def main():
         fence()
         dt = max_over_ranks(time.perf_counter() - t0)
         launch_ms = ev0.elapsed_time(ev1) / (steps * geo["launches"]) if steps else float("nan")
-        # algorithmic bytes of ONE launch: a (full) tile's drones x (timesteps per launch x 4P + 200)
-        bytes_per_launch = pop.local.bytes_per_launch(geo["steps_per_launch"], geo["tile_drones"])
+        # algorithmic bytes of the AVERAGE launch of the episode: every drone streams its genes T times and reads and
+        # writes its state once per launch (the last launch of a tile is shorter when K does not divide T, the last
+        # tile smaller when the tile does not divide n: averaging over the episode's launches accounts for both)
+        launches_per_tile = -(-T // geo["steps_per_launch"])
+        bytes_per_launch = (pop.local.bytes_per_launch(T, n_local) - pop.local.bytes_per_launch(0, n_local)
+                            + launches_per_tile * pop.local.bytes_per_launch(0, n_local)) / geo["launches"]
         achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "kernel": ("fly_split_kernel<float, L=%d, %s>" % (geo["waves_per_block"], "-".join(map(str, hidden)))
@@ -220,8 +227,9 @@ def main():
                                "episode, then the next tile): the genes, re-streamed every timestep, then come from HBM once per "
                                "episode and from the cache afterwards, so `achieved` (algorithmic bytes / time) can exceed the HBM "
                                "peak; `traffic` is what the memory-side counters saw",
-                "bytes_model": "drones_per_launch * (timesteps_per_launch * 4P + 200): genes once per timestep, the 25 state words "
-                               "read and written once per launch (they stay in registers in between); 4P + 200 per drone-step at 1"}
+                "bytes_model": "per launch, averaged over the episode's launches: drones x (timesteps x 4P + 200): genes once per "
+                               "timestep, the 25 state words read and written once per launch (they stay in registers in between); "
+                               "4P + 200 per drone-step at one timestep per launch"}
         return pop, records, dt, roof
 
     n_total_strong = args.drones
@@ -283,6 +291,16 @@ def main():
         torch.cuda.synchronize()
         roof["copy_ceiling_gbs"] = 10 * 2 * src_buf.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del src_buf, dst_buf
+
+    # The same population in whole-population launches: every timestep's genes from HBM (the HBM-bound figure next
+    # to the cache-blocked headline), when the headline run was tiled
+    if not args.no_extras and roof["tiles"] > 1:
+        _, _, dt_w, roof_w = measure(n_local, args.steps, 1, force_tile=n_local)
+        extras["whole_population_launches"] = {"value": n_local * world * T * args.steps / dt_w, "unit": "drone-steps/s",
+                                               "ms_per_step": dt_w / args.steps * 1e3,
+                                               "roofline": {k: roof_w[k] for k in ("achieved", "frac", "launch_us", "bytes_per_launch",
+                                                                                   "timesteps_per_launch", "wavefronts_per_block",
+                                                                                   "drones_per_launch", "launches_per_episode")}}
 
     # The shard one GPU owns when BASELINE's 65 536-drone population is spread over 8 (N = 1 only: with
     # N > 1 the strong_scaling object measures the real thing)

@@ -29,8 +29,10 @@ for r in range(rounds):
     respawn = bool(rng.random() < 0.5)
     sim = SimParams.reference(wind=rng.normal(0, 0.5, 3)) if rng.random() < 0.3 else None
     waves, k = int(rng.choice([1, 2, 4, 8])), int(rng.choice([1, 3, 16, 50, T]))
+    tile = int(rng.choice([64, 128, 192, 1024, 4096]))
     out = []
-    for kw in ("generic", dict(), dict(steps_per_launch=k, waves_per_block=waves), dict(engine="resident")):
+    f64 = hidden in Population.RESIDENT_SPECS_F64 and rng.random() < 0.25
+    for kw in ("generic", dict(), dict(steps_per_launch=k, waves_per_block=waves, tile_drones=tile), dict(engine="resident")):
         pop = Population(n, hidden, coins=coins, walls=walls, init_state=init, coin_respawn=respawn, sim=sim)
         pop.set_genomes(genes)
         if kw == "generic":
@@ -43,8 +45,16 @@ for r in range(rounds):
             pop.fly(T, **kw)
         out.append((pop.fstate.clone(), pop.istate.clone(), pop.records.clone()))
     same = all(torch.equal(a, b) for other in out[1:] for a, b in zip(out[0], other))
+    if f64:                                   # the float64 twins: resident engine against one launch per timestep
+        o64 = []
+        for engine in ("step", "resident"):
+            pop = Population(n, hidden, precision="f64", coins=coins, walls=walls, init_state=init, coin_respawn=respawn, sim=sim)
+            pop.set_genomes(genes)
+            pop.fly(min(T, 400), engine=engine)
+            o64.append((pop.fstate.clone(), pop.istate.clone(), pop.records.clone(), pop.distance.clone()))
+        same = same and all(torch.equal(a, b) for a, b in zip(*o64))
     crashed = float((out[0][1][2] & 1).float().mean())
-    print(f"round {r:3d} spec {str(hidden):14s} n={n:5d} T={T:5d} coins={len(coins):2d}{'+' if respawn else ' '} L={waves} K={k:4d} walls={0 if walls is None else len(walls):2d} crashed {crashed:.2f}  {'ok' if same else 'MISMATCH'}", flush=True)
+    print(f"round {r:3d} spec {str(hidden):14s} n={n:5d} T={T:5d} coins={len(coins):2d}{'+' if respawn else ' '} L={waves} K={k:4d} tile={tile:4d} walls={0 if walls is None else len(walls):2d} crashed {crashed:.2f}  {'ok' if same else 'MISMATCH'}", flush=True)
     bad += not same
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)

@@ -230,11 +230,14 @@ int ld_fly_step_f64(const ld_sim_params *sim, const ld_episode_params *ep, const
 
 /* `n_steps` iterations of that loop body in ONE launch (float32, layer specs with an unrolled
  * specialisation; others return LD_ERR_SPEC), with the launch geometry made explicit: the 64 drones
- * of a genome block are served by `waves_per_block` wavefronts of one workgroup (1, 2, 4 or 8; 0 =
- * chosen from n, the spec and n_steps).  Each wavefront streams a contiguous share of every layer's
- * rows (still one lane per drone, one coalesced 1 KiB line per gene word, every neuron's sum in gene
- * order), the layers' outputs cross wavefronts through LDS.  Small shards need this to fill the
- * chip: 8 192 drones are 128 wavefronts at one wavefront per block.  With n_steps > 1 the drone
+ * of a genome block are served by `waves_per_block` wavefronts (1, 2, 4, 8: one workgroup of that many;
+ * 16, 32: two / four workgroups of 8, each flying 32 / 16 of the block's drones; nets wider than 512
+ * gene words: 8, 16 = two / four workgroups of 4, 32 not available; 0 = chosen from n, the spec and
+ * n_steps).  Each wavefront of a workgroup streams a contiguous share of every layer's rows (still one
+ * lane per drone, one coalesced line per gene word, every neuron's sum in gene order), the layers'
+ * outputs cross wavefronts through LDS.  Small shards need this to fill the chip: 8 192 drones are 128
+ * wavefronts at one wavefront per block, and 128 workgroups on 256 CUs at one workgroup per block.
+ * With n_steps > 1 the drone
  * state stays in registers between timesteps and the genes are re-streamed every step (from L2 /
  * Infinity Cache when the shard's genomes fit there): no per-step kernel boundary and 200/n_steps
  * instead of 200 bytes of state traffic per drone-step.  Results are bit-identical to n_steps calls

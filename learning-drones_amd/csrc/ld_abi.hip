@@ -125,20 +125,28 @@ int dispatch_mlp(const ld_mlp_spec* spec, const Real* genomes, const Real* input
     return launch_mlp<Real, ld::GenericNet<Real, Fma>>(spec, genomes, inputs, outputs, n, stream);
 }
 
-// Wavefronts per 64-drone genome block for the split kernel (ld_split.hpp), from the measured grid
-// (scripts/ab_grid.py, profiles/r02_split_grid.json): a launch of several timesteps wants about two
-// wavefronts per SIMD chip-wide (2 048), a launch of one timestep about one (1 024: its fixed latency chain
-// -- state load, rigid-body step, barriers -- grows with the wavefronts per block).  L = 8 (256 registers per
-// wavefront: a 16-word ring instead of 32) is taken only where L = 4 would leave SIMDs empty; the 64-wide nets
-// stop at 4.
+// Wavefronts per 64-drone genome block for the split kernel (ld_split.hpp / ld_split.inc), from the measured
+// grids (scripts/ab_grid.py, scripts/ab_sub.py; profiles/r02_split_grid.json, r02_subblock_grid.json).  A launch
+// of several timesteps wants about two wavefronts per SIMD chip-wide (2 048), a launch of one timestep about
+// one (1 024: its fixed latency chain -- state load, rigid-body step, barriers -- grows with the wavefronts
+// per block).  Up to 4 the wavefronts share one workgroup.  Beyond: small shards leave CUs empty at one
+// workgroup per block (8 192 drones = 128 blocks on 256 CUs, each CU pulling its block's genes at the ~50 GB/s
+// one CU can draw from L2 / Infinity Cache), so a block is split over 2 or 4 workgroups of 8 wavefronts (of 4 for
+// the nets wider than 512 gene words): 8 192 x 32-32 8.65 -> 6.74 us per timestep, 4 096: 7.64 -> 5.74.
 int auto_waves_per_block(const ld_mlp_spec* spec, int64_t n, int32_t n_steps)
 {
     const int64_t blocks = (n + 63) / 64;
     const int64_t target = n_steps > 1 ? 2048 : 1024;
     int waves = 1;
     while (waves * 2 <= 4 && blocks * waves * 2 <= target) waves *= 2;
-    if (waves == 4 && blocks * 4 < 1024 && ld_mlp_words_per_drone(spec) <= 512) waves = 8;
-    return waves;
+    if (waves < 4 || blocks * 4 >= 1024) return waves;          // the chip is full with one workgroup of <= 4 per block
+    const bool wide = ld_mlp_words_per_drone(spec) > 512;
+    const int per_group = wide ? 4 : 8;                          // wavefronts per workgroup beyond 4
+    int groups = 1;                                              // workgroups per block
+    if (n_steps > 1)
+        while (groups < 4 && blocks * per_group * groups * 2 <= target) groups *= 2;
+    if (wide && groups == 1) return 4;
+    return per_group * groups;
 }
 
 // Drones [begin, end) of a population of n (begin a multiple of 64).
@@ -251,7 +259,7 @@ int rollout_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, con
                       int64_t tile_drones, void* stream)
 {
     if (timesteps < 0 || steps_per_launch < 0 || tile_drones < 0 || (tile_drones % 64) != 0) return LD_ERR_SIZE;
-    if (waves != 0 && waves != 1 && waves != 2 && waves != 4 && waves != 8) return LD_ERR_SIZE;
+    if (waves != 0 && waves != 1 && waves != 2 && waves != 4 && waves != 8 && waves != 16 && waves != 32) return LD_ERR_SIZE;
     int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
     if (rc || n == 0) return rc;
     if (!has_unrolled(*spec)) return LD_ERR_SPEC;
@@ -546,7 +554,8 @@ int ld_fly_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, cons
                      int32_t waves_per_block, void* stream)
 {
     if (n_steps < 0) return LD_ERR_SIZE;
-    if (waves_per_block != 0 && waves_per_block != 1 && waves_per_block != 2 && waves_per_block != 4 && waves_per_block != 8)
+    if (waves_per_block != 0 && waves_per_block != 1 && waves_per_block != 2 && waves_per_block != 4 && waves_per_block != 8 &&
+        waves_per_block != 16 && waves_per_block != 32)
         return LD_ERR_SIZE;
     const int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
     if (rc || n == 0 || n_steps == 0) return rc;

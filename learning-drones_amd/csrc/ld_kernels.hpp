@@ -51,8 +51,9 @@ template <int Block> struct TableRegs {
     static constexpr int kCoins = (LD_MAX_COINS * LD_COIN_STRIDE + Block - 1) / Block;
     static constexpr int kWalls = (LD_MAX_WALLS * LD_WALL_STRIDE + Block - 1) / Block;
     double c[kCoins], w[kWalls];
+    // `tid`: this thread's index among the Block threads that stage the tables
     template <typename Ep>
-    __device__ __forceinline__ void load(const Ep& ep, const double* __restrict__ coins, const double* __restrict__ walls)
+    __device__ __forceinline__ void load(const Ep& ep, const double* __restrict__ coins, const double* __restrict__ walls, int tid)
     {
         // unconditional loads at clamped indices (a predicated load sits in its own basic block and the
         // compiler then waits for it on the spot, serialising the state and gene latencies)
@@ -61,26 +62,26 @@ template <int Block> struct TableRegs {
         const int last_w = n_w > 0 ? n_w - 1 : 0;
 #pragma unroll
         for (int q = 0; q < kCoins; ++q) {
-            const int idx = threadIdx.x + q * Block;
+            const int idx = tid + q * Block;
             c[q] = coins[idx < n_c ? idx : n_c - 1];
         }
 #pragma unroll
         for (int q = 0; q < kWalls; ++q) {
-            const int idx = threadIdx.x + q * Block;
+            const int idx = tid + q * Block;
             w[q] = wsrc[idx < n_w ? idx : last_w];
         }
     }
     template <typename Real, typename Ep>
-    __device__ __forceinline__ void store(const Ep& ep, Tables<Real>& t) const
+    __device__ __forceinline__ void store(const Ep& ep, Tables<Real>& t, int tid) const
     {
 #pragma unroll
         for (int q = 0; q < kCoins; ++q) {
-            const int idx = threadIdx.x + q * Block;
+            const int idx = tid + q * Block;
             if (idx < ep.n_coins * LD_COIN_STRIDE) t.coins[idx] = (Real)c[q];
         }
 #pragma unroll
         for (int q = 0; q < kWalls; ++q) {
-            const int idx = threadIdx.x + q * Block;
+            const int idx = tid + q * Block;
             if (idx < ep.n_walls * LD_WALL_STRIDE) t.walls[idx] = (Real)w[q];
         }
     }

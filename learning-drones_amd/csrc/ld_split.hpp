@@ -121,7 +121,11 @@ __device__ __forceinline__ void split_barrier()
 #define LD_SPLIT_HEAD_L8 8
 #endif
 
-template <typename Real, bool Faithful, int L, int... H>
+// S > 1: a 64-drone genome block is served by S workgroups of L wavefronts, each flying 64 / S of its drones on
+// the first 64 / S lanes of its wavefronts (the other lanes leave at once).  A shard of 8 192 drones is 128
+// genome blocks: one workgroup per block occupies 128 of the 256 CUs, and each of those pulls its block's genes
+// at the most one CU can draw from L2 / Infinity Cache (~50 GB/s); two workgroups per block use every CU.
+template <typename Real, bool Faithful, int L, int S, int... H>
 __global__ void __launch_bounds__(64 * L)
 fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restrict__ coins,
                  const double* __restrict__ walls, const GeneWord<Real>* __restrict__ genomes,
@@ -145,9 +149,11 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
     __shared__ Tables<Real> tab;
     __shared__ Real xch[Plan::xch_rows][64];
 
+    constexpr int kLanes = 64 / S;                            // drones (= active lanes) per wavefront
     const int lane = threadIdx.x & 63;
+    if (S > 1 && lane >= kLanes) return;
     const int wave = L == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t gid = begin + (int64_t)blockIdx.x * 64 + lane;
+    const int64_t gid = begin + (int64_t)(blockIdx.x / S) * 64 + (blockIdx.x % S) * kLanes + lane;
     const bool valid = gid < end;
     const int64_t i = valid ? gid : end - 1;                  // tail lanes read the last drone, store nothing
 
@@ -159,8 +165,8 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
     DroneRegs<Real> d;
     load_drone<Real>(fstate, n, i, d);
     int64_t lane_offset = word_index(i, 0, Shape::W);
-    TableRegs<64 * L> table_regs;                             // coin / wall tables: requested now, staged below
-    table_regs.load(ep, coins, walls);
+    TableRegs<kLanes * L> table_regs;                         // coin / wall tables: requested now, staged below
+    table_regs.load(ep, coins, walls, wave * kLanes + lane);
 
     // ---- this wavefront's first D gene words, requested behind the state and the tables
     GeneWord<Real> ring[D];
@@ -193,7 +199,7 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
         if (t == 0) {
             int32_t status = status_loaded;
             asm volatile("" : "+v"(status));
-            table_regs.template store<Real>(ep, tab);         // older than the ring: waits for state + tables only
+            table_regs.template store<Real>(ep, tab, wave * kLanes + lane);   // older than the ring: waits for state + tables only
             split_barrier();
             dead0 = (status & 1) || !valid;                   // crashed earlier: frozen
             dead = dead0;
@@ -305,12 +311,12 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
     }
 }
 
-template <typename Real, bool Faithful, int L, int... H>
+template <typename Real, bool Faithful, int L, int S, int... H>
 int launch_fly_split(const ld_sim_params* sim, const ld_episode_params* ep, const double* coins, const double* walls,
                      const Real* genomes, Real* fstate, int32_t* istate, int64_t n, int64_t begin, int64_t end,
                      int32_t n_steps, hipStream_t stream)
 {
-    hipLaunchKernelGGL((fly_split_kernel<Real, Faithful, L, H...>), dim3(blocks_for(end - begin, 64)), dim3(64 * L), 0, stream,
+    hipLaunchKernelGGL((fly_split_kernel<Real, Faithful, L, S, H...>), dim3(blocks_for(end - begin, 64) * S), dim3(64 * L), 0, stream,
                        make_sim<Real>(*sim), make_ep<Real>(*ep), coins, walls,
                        reinterpret_cast<const GeneWord<Real>*>(genomes), fstate, istate, n, begin, end, n_steps);
     return check_launch("fly_split_kernel");

@@ -1,0 +1,4 @@
+#define LD_TAG 32_32_32
+#define LD_WIDTHS 32, 32, 32
+#define LD_SPLIT_ONLY_CASE 4
+#include "ld_split.inc"

@@ -1,4 +1,4 @@
 #define LD_TAG 48_48
 #define LD_WIDTHS 48, 48
-#define LD_SPLIT_ONLY_L 1
+#define LD_SPLIT_ONLY_CASE 16
 #include "ld_split.inc"

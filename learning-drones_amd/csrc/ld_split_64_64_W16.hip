@@ -1,4 +1,4 @@
 #define LD_TAG 64_64
 #define LD_WIDTHS 64, 64
-#define LD_SPLIT_ONLY_L 8
+#define LD_SPLIT_ONLY_CASE 16
 #include "ld_split.inc"

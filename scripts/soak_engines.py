@@ -28,7 +28,7 @@ for r in range(rounds):
     genes = genes[:n]
     respawn = bool(rng.random() < 0.5)
     sim = SimParams.reference(wind=rng.normal(0, 0.5, 3)) if rng.random() < 0.3 else None
-    waves, k = int(rng.choice([1, 2, 4, 8])), int(rng.choice([1, 3, 16, 50, T]))
+    waves, k = int(rng.choice([1, 2, 4, 8, 16])), int(rng.choice([1, 3, 16, 50, T]))
     tile = int(rng.choice([64, 128, 192, 1024, 4096]))
     out = []
     f64 = hidden in Population.RESIDENT_SPECS_F64 and rng.random() < 0.25

@@ -444,8 +444,8 @@ def test_resident_engine_is_bit_identical(Population, torch, hidden, n, T):
 @pytest.mark.parametrize("hidden", [(32, 32), (16, 16), (10, 10), (8, 10), (64, 64, 64), (16,), (32,), (64,), (8, 8),
                                     (24, 24), (48, 48), (64, 64), (32, 32, 32)])
 def test_split_waves_and_multistep_are_bit_identical(Population, torch, generic_kernels, hidden):
-    """ld_fly_steps_f32 (a genome block's 64 drones served by 1, 2, 4 or 8 wavefronts; several loop
-    iterations per launch) against one launch per timestep of the run-time-spec kernel, which shares no
+    """ld_fly_steps_f32 (a genome block's 64 drones served by 1 to 32 wavefronts in one, two or four
+    workgroups; several loop iterations per launch) against one launch per timestep of the run-time-spec kernel, which shares no
     code with it beyond the per-lane arithmetic: states, rewards, coins and flight times bit for bit, on
     stable, marginal and crashing genomes, with a partial last block, coins collected and a wall hit."""
     n, T = 200, 330
@@ -464,9 +464,10 @@ def test_split_waves_and_multistep_are_bit_identical(Population, torch, generic_
     generic_kernels(False)
     crashed = (ref.istate[2] & 1).bool()
     assert crashed.any() and not crashed.all()
-    for waves in (0, 1, 2, 4, 8):
+    wide = spec.words_per_drone > 512                             # nets wider than 512 gene words have no 32-wavefront case
+    for waves in (0, 1, 2, 4, 8, 16) + (() if wide else (32,)):
         for k in (1, 7, T):
-            if k == 1 and waves in (2, 4) and hidden != (32, 32):
+            if k == 1 and waves in (2, 4, 16) and hidden != (32, 32):
                 continue                                          # keep the run time down: every (waves, k) pair on 32-32
             pop = fresh()
             done = 0

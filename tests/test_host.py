@@ -170,7 +170,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ld_ga_select(C.byref(ga), C.byref(spec), None, 8, 0, 8, fake, fake, None) == NULL
     steps = lib.ld_fly_steps_f32                                 # multi-wavefront / multi-step fused launch
     assert steps(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, 8, -1, 0, None) == SIZE
-    assert steps(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, 8, 4, 3, None) == SIZE      # waves not 0/1/2/4/8
+    assert steps(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, 8, 4, 3, None) == SIZE      # waves not 0/1/2/4/8/16/32
     assert steps(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, 0, 4, 8, None) == OK
     assert steps(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, odd, fake, fake, 8, 4, 8, None) == ALIGN
     assert steps(C.byref(sim), C.byref(ep), C.byref(MlpSpec.from_hidden((12,))), fake, None, fake, fake, fake, 8, 4, 0, None) == SPEC
@@ -182,11 +182,11 @@ def test_argument_validation_without_gpu(lib):
     geo = lambda h, n, T: (lib.ld_fly_rollout_geometry_f32(C.byref(MlpSpec.from_hidden(h)), n, T, C.byref(k), C.byref(w), C.byref(m),
                                                             C.byref(tile)), k.value, w.value, m.value, tile.value)
     # config 3: 446 MB of genes > Infinity Cache -> four tiles of 16 384 drones (111 MB each), 4 wavefronts per block
-    assert geo((32, 32), 65536, 2000) == (OK, 64, 4, 128, 16384) and geo((32, 32), 8192, 2000) == (OK, 64, 8, 32, 8192)
+    assert geo((32, 32), 65536, 2000) == (OK, 64, 4, 128, 16384) and geo((32, 32), 8192, 2000) == (OK, 64, 16, 32, 8192)
     assert geo((32, 32), 32768, 4000) == (OK, 64, 4, 126, 16384)           # config 4 shard: 223 MB -> two tiles
     assert geo((32, 32), 16384, 2000) == (OK, 64, 4, 32, 16384)
     assert geo((64, 64, 64), 131072, 4000) == (OK, 64, 1, 63, 131072)     # 38 KB of genes per drone: a tile could not fill the chip
-    assert geo((64, 64, 64), 8192, 100) == (OK, 64, 4, 2, 8192) and geo((12,), 1000, 50) == (OK, 1, 1, 50, 1000)
+    assert geo((64, 64, 64), 8192, 100) == (OK, 64, 16, 2, 8192) and geo((12,), 1000, 50) == (OK, 1, 1, 50, 1000)
     assert geo((10, 10), 65536, 2000) == (OK, 64, 2, 32, 65536)           # 82 MB: fits as it is
     assert geo((10, 10), 1048576, 100)[4] == 65536
     assert lib.ld_fly_rollout_geometry_f32(C.byref(spec), 8, 8, None, None, None, None) == NULL
@@ -229,7 +229,7 @@ def test_runtime_specialisation_builds_and_registers(lib):
     k, w, m = C.c_int32(), C.c_int32(), C.c_int32()
     tile = C.c_int64()
     assert lib.ld_fly_rollout_geometry_f32(C.byref(spec), 8192, 2000, C.byref(k), C.byref(w), C.byref(m), C.byref(tile)) == 0
-    assert (k.value, w.value, m.value, tile.value) == (64, 8, 32, 8192)                   # the specialised spec takes the multi-step geometry
+    assert (k.value, w.value, m.value, tile.value) == (64, 16, 32, 8192)                   # the specialised spec takes the multi-step geometry
     assert lib.ld_debug_force_generic(1) == 0 and lib.ld_has_specialisation_f32(C.byref(spec)) == 0
     assert lib.ld_debug_force_generic(0) == 1
     # the entry points validate like the built-in ones (n == 0 is a no-op, no kernel is launched without a GPU)

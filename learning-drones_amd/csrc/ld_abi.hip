@@ -143,8 +143,9 @@ int auto_waves_per_block(const ld_mlp_spec* spec, int64_t n, int32_t n_steps)
     const bool wide = ld_mlp_words_per_drone(spec) > 512;
     const int per_group = wide ? 4 : 8;                          // wavefronts per workgroup beyond 4
     int groups = 1;                                              // workgroups per block
+    const int64_t group_target = wide ? 1024 : target;           // (64-64-64 at 8 192 drones: 51.5 / 43.8 / 59.5 us at 1 / 2 / 4)
     if (n_steps > 1)
-        while (groups < 4 && blocks * per_group * groups * 2 <= target) groups *= 2;
+        while (groups < 4 && blocks * per_group * groups * 2 <= group_target) groups *= 2;
     if (wide && groups == 1) return 4;
     return per_group * groups;
 }

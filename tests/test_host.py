@@ -186,7 +186,7 @@ def test_argument_validation_without_gpu(lib):
     assert geo((32, 32), 32768, 4000) == (OK, 64, 4, 126, 16384)           # config 4 shard: 223 MB -> two tiles
     assert geo((32, 32), 16384, 2000) == (OK, 64, 4, 32, 16384)
     assert geo((64, 64, 64), 131072, 4000) == (OK, 64, 1, 63, 131072)     # 38 KB of genes per drone: a tile could not fill the chip
-    assert geo((64, 64, 64), 8192, 100) == (OK, 64, 16, 2, 8192) and geo((12,), 1000, 50) == (OK, 1, 1, 50, 1000)
+    assert geo((64, 64, 64), 8192, 100) == (OK, 64, 8, 2, 8192) and geo((12,), 1000, 50) == (OK, 1, 1, 50, 1000)
     assert geo((10, 10), 65536, 2000) == (OK, 64, 2, 32, 65536)           # 82 MB: fits as it is
     assert geo((10, 10), 1048576, 100)[4] == 65536
     assert lib.ld_fly_rollout_geometry_f32(C.byref(spec), 8, 8, None, None, None, None) == NULL

@@ -20,6 +20,7 @@
 #pragma once
 
 #include <algorithm>
+#include <type_traits>
 
 #include "ld_kernels.hpp"
 
@@ -37,7 +38,42 @@ template <int L, int... H> struct ResidentLayout {
         return r;
     }
     static constexpr int kGeneRegs = reg_offset(Shape::n_layers);
+    // Register of gene k of the lane's q-th neuron of a layer.  Packed: the lane's neurons are taken two at a
+    // time and the pair's genes interleaved, (q even, k), (q odd, k) adjacent, so that one v_pk_fma_f32 advances
+    // both neurons' sums by input k (each half is an IEEE fma: the sums are bit-identical to the scalar chain).
+    // gfx950 issues a wave64 v_fma_f32 in 2 cycles and a v_pk_fma_f32 in 4 (scripts/micro/pk_fma_rate.hip), so
+    // packing does not raise the FMA rate; it pays where a lane has many neurons (>= 8 per layer: 15-32-4 at
+    // L = 2, 15-64-4 at L = 4: -18 / -21 % per episode, from halved instruction count and register moves) and
+    // costs 3-4 % where it leaves a lane one or two dependent chains (measured: profiles/r02_resident_lanes.json)
+    static constexpr bool packs(bool packed, int layer) { return packed && slots(layer) >= 8; }
+    static constexpr int reg_of(bool packed, int layer, int q, int k)
+    {
+        const int stride = Shape::dims[layer] + 1, paired = packs(packed, layer) ? slots(layer) / 2 * 2 : 0;
+        return reg_offset(layer) + (q < paired ? ((q / 2) * stride + k) * 2 + q % 2 : q * stride + k);
+    }
 };
+
+typedef float PackedPair __attribute__((ext_vector_type(2)));
+
+// Value of lane SRC of the caller's group of L lanes (L = 2, 4: quad_perm; L = 16: a DPP row, row_newbcast), as a
+// v_mov_b32_dpp: a layer's outputs stay in the registers of the lanes that computed them and the next layer
+// reads input k straight from lane k % L -- no LDS round trip (which costs a CU's one LDS pipe 8 cycles per
+// ds_read_b128 of a wavefront, shared by all its SIMDs, plus the wait).
+template <int L, int SRC> __device__ __forceinline__ float group_bcast(float v)
+{
+    static_assert(L == 2 || L == 4 || L == 16, "group_bcast: no single DPP control for this group size");
+    constexpr int ctrl = L == 16 ? 0x150 + SRC : L == 4 ? SRC * 0x55 : (SRC | SRC << 2 | (2 + SRC) << 4 | (2 + SRC) << 6);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true));
+}
+template <int L, int SRC> __device__ __forceinline__ double group_bcast(double v) { return v; }     // never taken (float32 only)
+// Which specs take it is measured, not derived (scripts/micro/dpp_rate.hip: a v_mov_b32_dpp costs 1.1, a
+// v_fmac_f32_dpp 1.6 plain FMAs on gfx950; scripts/time_resident.py, ms per 65 536 x 2 000 episode, LDS -> DPP):
+// 15-32-4 7.42 -> 6.99, 15-64-4 14.98 -> 13.2, 48-48 (32 768 x 1 000) 14.6 -> 13.3; but 32-32 22.1 -> 25.0 and
+// 16-16 6.06 -> 6.85: one DPP move per input pays only where many neurons of the lane consume it.
+template <int... H> struct ResidentDpp { static constexpr bool value = false; };
+template <> struct ResidentDpp<32> { static constexpr bool value = true; };
+template <> struct ResidentDpp<64> { static constexpr bool value = true; };
+template <> struct ResidentDpp<48, 48> { static constexpr bool value = true; };
 
 // A workgroup is one wavefront, and a wavefront's LDS operations execute in issue order, so the
 // exchange needs no hardware barrier: only the compiler must not move LDS accesses across it.
@@ -62,6 +98,9 @@ fly_resident_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __re
                     int32_t* __restrict__ istate, const int64_t n, const int32_t timesteps, int32_t* __restrict__ queue)
 {
     constexpr bool Fma = !Faithful;                       // float32: fma chain; float64: the reference's multiply, then add
+    constexpr bool Packed = Fma && std::is_same<Real, float>::value;      // two neurons per v_pk_fma_f32
+    // layer outputs cross the lanes of a group by DPP instead of LDS where one DPP control does it
+    constexpr bool Dpp = ResidentDpp<H...>::value && std::is_same<Real, float>::value && (L == 2 || L == 4 || L == 16);
     using Lay = ResidentLayout<L, H...>;
     using Shape = typename Lay::Shape;
     constexpr int G = Lay::kDrones;
@@ -100,7 +139,7 @@ fly_resident_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __re
                     static_for<0, n_in + 1>([&](auto kc) __attribute__((always_inline)) {
                         constexpr int k = decltype(kc)::value;
                         const int p = Shape::layer_offset(layer) + jj * (n_in + 1) + k;
-                        genes[Lay::reg_offset(layer) + q * (n_in + 1) + k] = genomes[word_index(drone, p >> 2, Shape::W) * 4 + (p & 3)];
+                        genes[Lay::reg_of(Packed, layer, q, k)] = genomes[word_index(drone, p >> 2, Shape::W) * 4 + (p & 3)];
                     });
                 });
             });
@@ -152,6 +191,7 @@ fly_resident_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __re
         for (int k = 0; k < 12; ++k) act[k] = e.s[k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) act[12 + k] = c[k];
+        Real yv[(MW + L - 1) / L];                         // Dpp: this lane's outputs of the previous layer
         static_for<0, Shape::n_layers>([&](auto lc) __attribute__((always_inline)) {
             constexpr int layer = decltype(lc)::value;
             constexpr int n_in = Shape::dims[layer], n_out = Shape::dims[layer + 1];
@@ -159,31 +199,68 @@ fly_resident_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __re
             // the lane's neurons advance together, input by input: Q independent fma chains in flight
             // (each neuron's own sum still runs in gene order, so the result is unchanged)
             constexpr int Q = Lay::slots(layer);
-            constexpr int stride = n_in + 1;
+            if constexpr (Dpp && layer > 0) {              // input k = output k of the previous layer: slot k / L of lane k % L
+                static_for<0, n_in>([&](auto kc) __attribute__((always_inline)) {
+                    constexpr int k = decltype(kc)::value;
+                    act[k] = group_bcast<L, k % L>(yv[k / L]);
+                });
+            }
+            constexpr int QP = Lay::packs(Packed, layer) ? Q / 2 : 0;   // pairs of neurons; the odd one out (and float64) stay scalar
             Real acc[Q];
-            static_for<0, Q>([&](auto qc) __attribute__((always_inline)) {
+            if constexpr (QP > 0) {
+                PackedPair acc2[QP];
+                static_for<0, n_in>([&](auto kc) __attribute__((always_inline)) {
+                    constexpr int k = decltype(kc)::value;
+                    const PackedPair x = {(float)act[k], (float)act[k]};
+                    static_for<0, QP>([&](auto pc) __attribute__((always_inline)) {
+                        constexpr int r = Lay::reg_of(true, layer, 2 * decltype(pc)::value, k);
+                        const PackedPair w = {(float)genes[r], (float)genes[r + 1]};
+                        const PackedPair zero = {0.0f, 0.0f};
+                        acc2[decltype(pc)::value] = __builtin_elementwise_fma(w, x, k == 0 ? zero : acc2[decltype(pc)::value]);
+                    });
+                });
+                static_for<0, QP>([&](auto pc) __attribute__((always_inline)) {
+                    acc[2 * decltype(pc)::value] = acc2[decltype(pc)::value].x;
+                    acc[2 * decltype(pc)::value + 1] = acc2[decltype(pc)::value].y;
+                });
+            }
+            static_for<2 * QP, Q>([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value;
-                acc[q] = mac<Real, Fma>(genes[Lay::reg_offset(layer) + q * stride], act[0], (Real)0);
+                acc[q] = mac<Real, Fma>(genes[Lay::reg_of(Packed, layer, q, 0)], act[0], (Real)0);
             });
             static_for<1, n_in>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;
-                static_for<0, Q>([&](auto qc) __attribute__((always_inline)) {
+                static_for<2 * QP, Q>([&](auto qc) __attribute__((always_inline)) {
                     constexpr int q = decltype(qc)::value;
-                    acc[q] = mac<Real, Fma>(genes[Lay::reg_offset(layer) + q * stride + k], act[k], acc[q]);
+                    acc[q] = mac<Real, Fma>(genes[Lay::reg_of(Packed, layer, q, k)], act[k], acc[q]);
                 });
             });
             static_for<0, Q>([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value;
-                const Real sum = acc[q] + genes[Lay::reg_offset(layer) + q * stride + n_in];
+                const Real sum = acc[q] + genes[Lay::reg_of(Packed, layer, q, n_in)];
                 const Real y = last ? sigmoid04<Real>(sum) : relu<Real>(sum);
-                const int j = l + q * L;
-                if (j < n_out) xch[layer & 1][g][j] = y;
+                if constexpr (Dpp) {
+                    acc[q] = y;
+                } else {
+                    const int j = l + q * L;
+                    if (j < n_out) xch[layer & 1][g][j] = y;
+                }
             });
-            LD_RES_SYNC();                                 // one wavefront per workgroup: orders LDS write -> read
+            if constexpr (Dpp) {
+                static_for<0, Q>([&](auto qc) __attribute__((always_inline)) { yv[decltype(qc)::value] = acc[decltype(qc)::value]; });
+                if constexpr (last) {
+                    static_for<0, n_out>([&](auto kc) __attribute__((always_inline)) {
+                        constexpr int k = decltype(kc)::value;
+                        act[k] = group_bcast<L, k % L>(yv[k / L]);
+                    });
+                }
+            } else {
+                LD_RES_SYNC();                             // one wavefront per workgroup: orders LDS write -> read
 #pragma unroll
-            for (int k = 0; k < n_out; ++k) act[k] = xch[layer & 1][g][k];
+                for (int k = 0; k < n_out; ++k) act[k] = xch[layer & 1][g][k];
+            }
         });
-        LD_RES_SYNC();                                     // the next step's first layer reuses buffer 0
+        if constexpr (!Dpp) LD_RES_SYNC();                 // the next step's first layer reuses buffer 0
 
         const bool stepping = active && !crashed_state;    // commit, as fly_step_kernel does
         if (stepping) {

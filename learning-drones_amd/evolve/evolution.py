@@ -34,11 +34,63 @@ def save_drone(drone: Drone, path: str, **extra) -> None:
         json.dump(doc, f)
 
 
+def _jsonpickle_array(node, state) -> np.ndarray:
+    """One numpy array out of a jsonpickle document, data only (nothing is imported or called from the file).
+    jsonpickle (1.4.1, the reference's pin, without its numpy extension, which the reference never registers)
+    writes an ndarray through `ndarray.__reduce__`: {"py/reduce": [_reconstruct, args, STATE, ...]} with
+    STATE = {"py/tuple": [version, {"py/tuple": shape}, dtype, fortran_order, {"py/b64": raw bytes}]} and dtype
+    either a nested py/reduce whose first argument is the type string ("f8") or a {"py/id": n} back-reference to
+    the dtype object of an earlier array.  The numpy-extension spelling ({"py/object": "numpy.ndarray",
+    "values": [...]}) and plain nested lists are accepted too."""
+    import base64
+    if isinstance(node, list):
+        return np.asarray(node, dtype=np.float64)
+    if "values" in node:
+        return np.asarray(node["values"], dtype=node.get("dtype", "float64")).astype(np.float64)
+    st = node["py/reduce"][2]
+    st = st["py/tuple"] if isinstance(st, dict) else st
+    _, shape, dtype, fortran, data = st
+    shape = tuple(shape["py/tuple"] if isinstance(shape, dict) else shape)
+    if isinstance(dtype, dict) and "py/reduce" in dtype:
+        args = dtype["py/reduce"][1]
+        code = (args["py/tuple"] if isinstance(args, dict) else args)[0]
+        order = dtype["py/reduce"][2]
+        order = (order["py/tuple"] if isinstance(order, dict) else order)[1] if order else "<"
+        state["dtype"] = np.dtype(code).newbyteorder(order if order in "<>" else "=")
+    raw = base64.b64decode(data["py/b64"]) if isinstance(data, dict) else bytes(data)
+    a = np.frombuffer(raw, dtype=state.get("dtype", np.dtype("<f8")))
+    return a.reshape(shape, order="F" if fortran else "C").astype(np.float64)
+
+
+def read_reference_checkpoint(doc):
+    """(layer_spec, weights) from the reference's `best_drone_*.json` (evolution.py:85-87: a jsonpickle string of
+    the whole Drone object, json.dump'ed once more).  Restated from jsonpickle's documented encoding; jsonpickle
+    is not importable here and the reference ships no checkpoint file, so this reader is checked against a
+    hand-written document of that shape only (tests/test_dropin_host.py) -- parity unpinned."""
+    if isinstance(doc, str):
+        doc = json.loads(doc)
+    ctrl = doc["controller"]
+    state = {}
+    weights = [_jsonpickle_array(w, state) for w in ctrl["weights"]]
+    spec = {int(k): int(v) for k, v in ctrl["layer_spec"].items() if not str(k).startswith("py/")}
+    return spec, weights
+
+
 def load_drone(path: str, precision: str = "f64") -> Drone:
+    """A drone from a checkpoint: this package's plain-JSON layout (save_drone) or the reference's jsonpickle
+    document (read data-only, see read_reference_checkpoint)."""
     from ..evolve.brain import NeuralNetwork
     from ..params import unflatten_weights
     with open(path) as f:
         doc = json.load(f)
+    if isinstance(doc, str) or "py/object" in doc:
+        spec, weights = read_reference_checkpoint(doc)
+        d = Drone(visualize=False, n_servers=0, precision=precision)
+        d.controller = NeuralNetwork(layer_spec={k: v for k, v in spec.items() if k != 0}, precision=precision)
+        if [w.shape for w in weights] != [w.shape for w in d.controller.weights]:
+            raise ValueError(f"{path}: weight shapes {[w.shape for w in weights]} do not match layer_spec {spec}")
+        d.controller.weights = weights
+        return d
     d = Drone(visualize=False, n_servers=0, precision=precision)
     d.controller = NeuralNetwork(layer_spec={int(k): v for k, v in doc["layer_spec"].items()}, precision=precision)
     d.controller.weights = unflatten_weights(np.asarray(doc["genes"]), d.controller.spec)

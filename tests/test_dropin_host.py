@@ -1,6 +1,7 @@
 """Host-side drop-in parity (no GPU): the mirrors of Drone / NeuralNetwork / evolve.util draw from
 numpy's global random stream in the reference's order, so seeded runs reproduce the reference's
 genomes, selections, cuts and mutations bit for bit (golden G3 / G6)."""
+import json
 import numpy as np
 import pytest
 
@@ -100,3 +101,38 @@ def test_reset_restores_reference_defaults():
     d.reset()
     assert (d.reward, d.crashed, d.coins, d.flight_time, d.distance_to_coin) == (0, False, 0, 0, np.inf)
     assert np.array_equal(d.position.ravel(), [0, 0, 10]) and np.array_equal(d.thrust.ravel(), [0, 0, 0, 0])
+
+
+def _jsonpickle_ndarray(a, first):
+    """An ndarray the way jsonpickle 1.4.1 writes it without its numpy extension (through ndarray.__reduce__);
+    every array after the first refers to the first one's dtype object by py/id."""
+    import base64
+    dtype = ({"py/reduce": [{"py/type": "numpy.dtype"}, {"py/tuple": ["f8", 0, 1]},
+                            {"py/tuple": [3, "<", None, None, None, -1, -1, 0]}, None, None]} if first else {"py/id": 7})
+    return {"py/reduce": [{"py/function": "numpy.core.multiarray._reconstruct"},
+                          {"py/tuple": [{"py/type": "numpy.ndarray"}, {"py/tuple": [0]}, {"py/b64": "Yg=="}]},
+                          {"py/tuple": [1, {"py/tuple": list(a.shape)}, dtype, False,
+                                        {"py/b64": base64.b64encode(np.ascontiguousarray(a, dtype="<f8").tobytes()).decode()}]},
+                          None, None]}
+
+
+def test_reference_checkpoint_reader(tmp_path):
+    """evolution.py:85-87 writes json.dump(jsonpickle.encode(drone)): read data-only (parity unpinned: the document
+    is hand-written to jsonpickle's documented shape; jsonpickle itself is not importable here)."""
+    from learning_drones_amd.evolve.evolution import read_reference_checkpoint
+    rng = np.random.default_rng(5)
+    weights = [rng.normal(size=(8, 16)), rng.normal(size=(10, 9)), rng.normal(size=(4, 11))]
+    doc = {"py/object": "drone.drone.Drone", "visualize": False, "reward": 1234,
+           "controller": {"py/object": "evolve.brain.NeuralNetwork", "n_layers": 3,
+                          "layer_spec": {"1": 8, "2": 10, "3": 4, "0": 15},
+                          "weights": [_jsonpickle_ndarray(w, i == 0) for i, w in enumerate(weights)]}}
+    path = tmp_path / "best_drone_ref.json"
+    path.write_text(json.dumps(json.dumps(doc)))                     # the reference dumps the jsonpickle STRING
+    spec, got = read_reference_checkpoint(json.loads(path.read_text()))
+    assert spec == {1: 8, 2: 10, 3: 4, 0: 15}
+    assert all(np.array_equal(a, b) for a, b in zip(got, weights))
+    # the numpy-extension spelling and plain lists
+    doc["controller"]["weights"] = [{"py/object": "numpy.ndarray", "dtype": "float64", "values": w.tolist()} for w in weights]
+    assert all(np.array_equal(a, b) for a, b in zip(read_reference_checkpoint(doc)[1], weights))
+    doc["controller"]["weights"] = [w.tolist() for w in weights]
+    assert all(np.array_equal(a, b) for a, b in zip(read_reference_checkpoint(json.dumps(doc))[1], weights))

@@ -78,6 +78,27 @@ def test_evolve_two_generations(tmp_path):
     assert np.array_equal(again.genes, best.genes)
 
 
+def test_reference_format_checkpoint_replays(tmp_path):
+    """A best_drone_*.json in the reference's layout (evolution.py:85-87, jsonpickle string dumped as JSON) loads
+    data-only and flies like a Drone built from the same weights (fly_best_drone.py:10-16)."""
+    import json
+    from test_dropin_host import _jsonpickle_ndarray
+    from learning_drones_amd.drone.drone import Drone
+    from learning_drones_amd.evolve.evolution import load_drone
+    from learning_drones_amd.flight import fly
+    np.random.seed(3)
+    d = Drone(visualize=False, n_servers=0)
+    doc = {"py/object": "drone.drone.Drone", "controller": {"py/object": "evolve.brain.NeuralNetwork",
+           "layer_spec": {str(k): v for k, v in d.controller.layer_spec.items()},
+           "weights": [_jsonpickle_ndarray(w, i == 0) for i, w in enumerate(d.controller.weights)]}}
+    path = tmp_path / "best_drone_01_01_2020.json"
+    path.write_text(json.dumps(json.dumps(doc)))
+    again = load_drone(str(path))
+    assert all(np.array_equal(a, b) for a, b in zip(again.controller.weights, d.controller.weights))
+    fly(d, timesteps=300); fly(again, timesteps=300)
+    assert (again.reward, again.coins, again.flight_time, again.crashed) == (d.reward, d.coins, d.flight_time, d.crashed)
+
+
 # ------------------------------------------------------------------------------------------- device GA (SURVEY 8f-1)
 def _breed_once(n, hidden, fitness, ga, elite_slot=None, seed_genes=0):
     import torch

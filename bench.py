@@ -113,6 +113,8 @@ def main():
                     "~120 MB of genes when the population's genes exceed the Infinity Cache; the --drones value = no tiling)")
     ap.add_argument("--specialise", action="store_true", help="compile the unrolled kernels for --hidden at first use if the "
                     "library does not ship them (learning_drones_amd.specialise)")
+    ap.add_argument("--walls", type=int, default=0, help="number of wall boxes (BASELINE config 5 has walls: objects/walls.py is "
+                    "empty in the reference, so the boxes are this build's: slabs beside the flight corridor, tested every step, never hit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline rollout and its roofline (for rocprofv3 "
                     "runs: keeps every fused launch in the trace a full, live-population launch of the headline geometry)")
@@ -154,6 +156,11 @@ def main():
     if args.drones % world and (args.strong or world > 1):
         raise SystemExit("--drones must be divisible by the number of GPUs (strong-scaling split)")
 
+    walls = None
+    if args.walls:
+        import numpy as np
+        walls = np.array([[60.0 + 3 * k, -50.0, 0.0, 61.0 + 3 * k, 50.0, 80.0] for k in range(args.walls)])
+
     def fence():
         if dist:
             dist.barrier()
@@ -176,7 +183,7 @@ def main():
         """`steps` timed episodes of a population of n_local drones per rank: barrier + synchronize on both
         sides, wall time = max over ranks; the fused launches' average duration from HIP events on the
         launch stream over the same region."""
-        pop = ShardedPopulation(n_local * world, hidden, coins=coin_chain_reference(args.coins), precision="f32",
+        pop = ShardedPopulation(n_local * world, hidden, coins=coin_chain_reference(args.coins), precision="f32", walls=walls,
                                 device=device, process_group=dist.group.WORLD if dist else None, specialise=args.specialise)
         assert pop.local.n == n_local
         pop.local.set_genomes(make_genomes(torch, n_local, hidden, device, seed=rank))
@@ -410,8 +417,8 @@ def main():
     known = {(65536, 2000, (32, 32), 3): "BASELINE config 3", (1024, 2000, (16, 16), 1): "BASELINE config 2",
              (32768, 4000, (32, 32), 3): "BASELINE config 4 (one GPU's shard)",
              (8192, 2000, (32, 32), 3): "BASELINE target population (65 536 drones) spread over 8 GPUs: one GPU's shard",
-             (131072, 4000, (64, 64, 64), 5): "BASELINE config 5 (one GPU's shard, no walls)"}
-    config_name = known.get((n_local, T, hidden, args.coins), "custom workload")
+             (131072, 4000, (64, 64, 64), 5): "BASELINE config 5 (one GPU's shard)"}
+    config_name = known.get((n_local, T, hidden, args.coins), "custom workload") + (f", {args.walls} wall boxes" if args.walls else "")
 
     if rank == 0:
         n_total = n_local * world
@@ -426,7 +433,7 @@ def main():
                                    f"({roof['launches_per_episode']} fused launches of {roof['timesteps_per_launch']} timesteps x "
                                    f"{roof['drones_per_launch']} drones + finalize"
                                    + (" + RCCL all-gather of fitness records)" if world > 1 else ")"),
-                       "population": n_total, "timesteps": T, "hidden": list(hidden), "coins": args.coins,
+                       "population": n_total, "timesteps": T, "hidden": list(hidden), "coins": args.coins, "walls": args.walls,
                        "parallelism": f"population sharded x{world}, no data-path collective inside the rollout"},
             "ranks_seen": ranks_seen, "records": out_records,
             "strong_scaling": strong,

@@ -11,7 +11,7 @@ declare -A ARGS=(
   [shard8]=" --drones 8192"
   [c4]=" --drones 32768 --timesteps 4000"
   [c2]=" --drones 1024 --hidden 16,16 --coins 1"
-  [c5]=" --drones 131072 --timesteps 400 --hidden 64,64,64 --coins 5"
+  [c5]=" --drones 131072 --timesteps 400 --hidden 64,64,64 --coins 5 --walls 4"
   [gen12]=" --hidden 12,12"
   [jit12]=" --hidden 12,12 --specialise"
 )

@@ -377,7 +377,7 @@ int breed_impl(const ld_ga_params* ga, const ld_mlp_spec* spec, const Real* src,
     if (!aligned16(src) || !aligned16(dst) || (elite && !aligned16(elite))) return LD_ERR_ALIGN;
     const ld::LayerTable lt = ld::layer_table(*spec);
     const int64_t W = (lt.offset[lt.n_layers] + 3) / 4;
-    hipLaunchKernelGGL((ld::ga_breed_kernel<Real>), dim3(blocks_for(W * n_children, 256)), dim3(256), 0,
+    hipLaunchKernelGGL((ld::ga_breed_kernel<Real>), dim3(blocks_for(n_children, 256), (unsigned)W), dim3(256), 0,
                        static_cast<hipStream_t>(stream), *ga, lt, reinterpret_cast<const ld::GeneWord<Real>*>(src),
                        n_per_segment, parents, cuts, reinterpret_cast<const ld::GeneWord<Real>*>(elite), child_begin,
                        n_children, order, reinterpret_cast<ld::GeneWord<Real>*>(dst));

@@ -81,7 +81,9 @@ ga_select_kernel(const ld_ga_params ga, const LayerTable lt, const int32_t* __re
     }
 }
 
-// One thread per (word, child).
+// One thread per (word, child): blockIdx.y is the gene word, so the word index -- and with it the layer every
+// one of its four genes belongs to -- is uniform over the block (scalar registers, no per-lane search), and
+// the child index needs no division.
 template <typename Real>
 __global__ void __launch_bounds__(256)
 ga_breed_kernel(const ld_ga_params ga, const LayerTable lt, const GeneWord<Real>* __restrict__ src,
@@ -91,9 +93,9 @@ ga_breed_kernel(const ld_ga_params ga, const LayerTable lt, const GeneWord<Real>
 {
     const int P = lt.offset[lt.n_layers];
     const int64_t W = (P + 3) / 4;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= W * n_children) return;
-    const int64_t w = t / n_children, slot = t % n_children;
+    const int64_t w = blockIdx.y;
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_children) return;
     // `order` places child order[slot] of this shard (its parents, cuts and random draws follow the CHILD,
     // not the slot) into genome slot `slot`: any placement yields the same set of children
     const int64_t c = order ? order[slot] : slot;
@@ -102,22 +104,30 @@ ga_breed_kernel(const ld_ga_params ga, const LayerTable lt, const GeneWord<Real>
         dst[word_index(slot, w, W)] = elite[w];
         return;
     }
+    const uint32_t per_segment = (uint32_t)n_per_segment;
     const int64_t blocks_per_segment = (n_per_segment + kGenomeBlock - 1) / kGenomeBlock;
-    auto word_of = [&](int64_t g) {
-        const int64_t seg = g / n_per_segment, slot = g % n_per_segment;
-        return src[seg * blocks_per_segment * W * kGenomeBlock + word_index(slot, w, W)];
+    auto word_of = [&](int32_t g) {
+        const uint32_t seg = (uint32_t)g < per_segment ? 0u : (uint32_t)g / per_segment;      // one segment: no division
+        const uint32_t s = (uint32_t)g - seg * per_segment;
+        return src[seg * blocks_per_segment * W * kGenomeBlock + word_index(s, w, W)];
     };
     const int32_t pa = parents[c], pb = parents[c ^ 1];
     GeneWord<Real> v = word_of(pa);
-    // crossover: genes at or beyond the layer's cut come from the pair partner's parent
+    // crossover: genes at or beyond the layer's cut come from the pair partner's parent.  The layer of each
+    // of the word's four genes is block-uniform: the walk below is scalar, and a cut is loaded once per layer
+    // the word touches (one, at layer boundaries two)
+    int l = 0;
+    while (l + 1 < lt.n_layers && (int)(4 * w) >= lt.offset[l + 1]) ++l;
+    int32_t cut = cuts[(c / 2) * lt.n_layers + l];
     bool need_b = false;
     bool from_b[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int p = (int)(4 * w) + j;
-        int l = 0;
-        while (l + 1 < lt.n_layers && p >= lt.offset[l + 1]) ++l;
-        const int32_t cut = cuts[(c / 2) * lt.n_layers + l];
+        while (l + 1 < lt.n_layers && p >= lt.offset[l + 1]) {
+            ++l;
+            cut = cuts[(c / 2) * lt.n_layers + l];
+        }
         from_b[j] = (p < P) && cut >= 0 && (p - lt.offset[l]) >= cut;
         need_b = need_b || from_b[j];
     }

@@ -1,7 +1,6 @@
 """A/B of the fused step kernels on one GPU: per-launch time and algorithmic TB/s for
 (drones, layer spec, wavefronts per block, steps per launch), HIP events on the launch stream.
-    python scripts/ab_split.py [--quick]
-LD_STEP_LEGACY=1 in the environment routes Population.step() to the one-wavefront fly_step_kernel."""
+    python scripts/ab_split.py [--quick]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,7 +22,7 @@ def measure(pop, fn, launches, steps_per_launch=1):
 cases = [((32, 32), n) for n in (1024, 4096, 8192, 16384, 32768, 49152, 65536, 131072)] + \
         [((16, 16), 1024), ((16, 16), 8192), ((64, 64, 64), 8192), ((64, 64, 64), 16384), ((64, 64, 64), 131072), ((10, 10), 65536)]
 if "--quick" in sys.argv: cases = [((32, 32), 8192), ((32, 32), 32768), ((32, 32), 65536), ((16, 16), 1024)]
-legacy = bool(os.environ.get("LD_STEP_LEGACY"))
+legacy = False                                   # (the one-wavefront float32 step kernel this compared against is gone)
 out = []
 for hidden, n in cases:
     pop = Population(n, hidden, coins=coin_chain_reference(3))

@@ -111,8 +111,10 @@ def main():
     ap.add_argument("--waves-per-block", type=int, default=0, help="wavefronts per 64-drone genome block (0 = the library's choice)")
     ap.add_argument("--tile-drones", type=int, default=0, help="drones per tile of the rollout (0 = the library's choice: tiles of "
                     "~120 MB of genes when the population's genes exceed the Infinity Cache; the --drones value = no tiling)")
-    ap.add_argument("--specialise", action="store_true", help="compile the unrolled kernels for --hidden at first use if the "
-                    "library does not ship them (learning_drones_amd.specialise)")
+    ap.add_argument("--specialise", dest="specialise", action="store_true", default=None, help="compile the unrolled kernels for "
+                    "--hidden at first use if the library does not ship them (learning_drones_amd.specialise); the default is "
+                    "Population's: automatic for large float32 populations when hipcc is there")
+    ap.add_argument("--no-specialise", dest="specialise", action="store_false", help="stay on the run-time-spec kernels")
     ap.add_argument("--walls", type=int, default=0, help="number of wall boxes (BASELINE config 5 has walls: objects/walls.py is "
                     "empty in the reference, so the boxes are this build's: slabs beside the flight corridor, tested every step, never hit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -138,11 +138,22 @@ def build_specialisation(hidden, verbose: bool = False) -> Path:
     newest = max(p.stat().st_mtime for p in HEADERS + [Path(__file__)])
     if lib.exists() and src.exists() and src.read_text() == text and lib.stat().st_mtime >= newest:
         return lib
-    src.write_text(text)
-    cmd = [hipcc(), *FLAGS, "-shared", str(src), "-o", str(lib)]
+    # several ranks of one job may get here at once: each compiles its own copy and renames it into place
+    # (os.replace is atomic; the copies are identical)
+    mine = JIT_DIR / f"ld_spec_{tag}.{os.getpid()}.hip"
+    mine.write_text(text)
+    tmp = JIT_DIR / f"libld_spec_{tag}.{os.getpid()}.so"
+    cmd = [hipcc(), *FLAGS, "-shared", str(mine), "-o", str(tmp)]
     if verbose:
         print("[learning-drones_amd] " + " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, lib)
+        os.replace(mine, src)
+    finally:
+        for leftover in (tmp, mine):
+            if leftover.exists():
+                leftover.unlink()
     return lib
 
 

@@ -29,6 +29,16 @@ def _torch():
     return torch
 
 
+def _auto_specialise_enabled() -> bool:
+    """The default (specialise=None) compiles missing layer specs when hipcc is on the machine and the
+    environment does not say LD_SPECIALISE=0."""
+    import os
+    import shutil
+    if os.environ.get("LD_SPECIALISE", "1") == "0":
+        return False
+    return bool(shutil.which("hipcc")) or os.path.exists("/opt/rocm/bin/hipcc")
+
+
 class Population:
     """n drones with one controller genome each, resident on one GPU.
 
@@ -36,17 +46,22 @@ class Population:
     reference's float32 rounding points; validation mode, 2x the bytes).
     """
 
+    AUTO_SPECIALISE_MIN_DRONES = 4096      # below this a 12-60 s compile does not pay for itself
+
     def __init__(self, n: int, hidden: Iterable[int] = (10, 10), *, precision: str = "f32",
                  device: Optional[str] = None, sim: Optional[SimParams] = None,
                  episode: Optional[EpisodeParams] = None, coins: Optional[np.ndarray] = None,
                  walls: Optional[np.ndarray] = None, init_state: Optional[Sequence[float]] = None,
-                 coin_respawn: Optional[bool] = None, specialise: bool = False):
+                 coin_respawn: Optional[bool] = None, specialise: Optional[bool] = None):
         """coins=None is the reference's episode: the first coin (5, 5, 10) and the unbounded respawn
         chain behind it (flight/__init__.py:25,47-52).  A coin table given explicitly is a finite chain
         (nothing respawns after its last row) unless coin_respawn=True continues it by the reference rule.
         specialise=True compiles the unrolled float32 kernels for this layer spec if the library does not ship
         them (_native.specialise: hipcc at first use, cached; identical results, about twice the throughput of
-        the run-time-spec kernels)."""
+        the run-time-spec kernels) and raises if that fails; False never does; None (the default) does it for
+        float32 populations of AUTO_SPECIALISE_MIN_DRONES or more when hipcc is there, and carries on with the
+        run-time-spec kernels (with a warning) when the compile fails.  LD_SPECIALISE=0 in the environment turns
+        the automatic case off."""
         torch = _torch()
         _native.require_gpu()
         if precision not in ("f32", "f64"):
@@ -55,8 +70,17 @@ class Population:
         if self.n < 0:
             raise ValueError("n must be >= 0")
         self.spec = hidden if isinstance(hidden, MlpSpec) else MlpSpec.from_hidden(hidden)
+        if precision == "f32" and specialise is None:
+            specialise = "auto" if self.n >= self.AUTO_SPECIALISE_MIN_DRONES and _auto_specialise_enabled() else False
         if specialise and precision == "f32":
-            _native.specialise(self.spec.hidden_widths)
+            try:
+                _native.specialise(self.spec.hidden_widths)
+            except Exception as exc:                              # noqa: BLE001 -- hipcc missing / compile error
+                if specialise != "auto":
+                    raise
+                import warnings
+                warnings.warn(f"learning-drones_amd: no run-time specialisation for layer spec {self.spec.hidden_widths} "
+                              f"({exc}); using the run-time-spec kernels", RuntimeWarning)
         self.precision = precision
         self.dtype = torch.float32 if precision == "f32" else torch.float64
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")

@@ -15,7 +15,7 @@ scripts/profile_config.sh shard8 --drones 8192                                  
 scripts/profile_config.sh c4 --drones 32768 --timesteps 4000                       # config 4 shard
 scripts/profile_config.sh c2 --drones 1024 --hidden 16,16 --coins 1                # config 2
 scripts/profile_config.sh c5 --drones 131072 --timesteps 400 --hidden 64,64,64 --coins 5 --walls 4   # config 5 shard (short episode)
-scripts/profile_config.sh gen12 --hidden 12,12                                     # run-time-spec kernel
+scripts/profile_config.sh gen12 --hidden 12,12 --no-specialise                                  # run-time-spec kernel
 scripts/profile_config.sh jit12 --hidden 12,12 --specialise                        # the same spec specialised at run time
 # effective shader clock of the profiled headline run: GRBM_GUI_ACTIVE / 8 / kernel duration
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/c3_clock -- python3 bench.py --steps 1 --warmup 0 --no-extras > $out/c3_clock.json 2> $out/c3_clock.err

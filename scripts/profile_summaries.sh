@@ -12,7 +12,7 @@ declare -A ARGS=(
   [c4]=" --drones 32768 --timesteps 4000"
   [c2]=" --drones 1024 --hidden 16,16 --coins 1"
   [c5]=" --drones 131072 --timesteps 400 --hidden 64,64,64 --coins 5 --walls 4"
-  [gen12]=" --hidden 12,12"
+  [gen12]=" --hidden 12,12 --no-specialise"
   [jit12]=" --hidden 12,12 --specialise"
 )
 for tag in c3 c3_whole c3_k1 shard8 c4 c2 c5 gen12 jit12; do

@@ -1,8 +1,13 @@
+import os
 import sys
 from pathlib import Path
 
 import numpy as np
 import pytest
+
+# The tests choose their kernels explicitly (specialise=True / the generic_kernels fixture): the automatic run-time
+# specialisation of large float32 populations would put a hipcc run behind every odd layer spec the suite uses.
+os.environ.setdefault("LD_SPECIALISE", "0")
 
 REPO = Path(__file__).resolve().parent.parent
 GOLDEN = REPO / "tests" / "golden"

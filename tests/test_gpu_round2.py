@@ -472,3 +472,30 @@ def test_runtime_specialised_spec_equals_generic_kernels(Population, torch, gene
     assert torch.equal(pop.records, ref.records) and torch.equal(pop.fstate, ref.fstate)
     crashed = (ref.istate[2] & 1).bool()
     assert crashed.any() and not crashed.all()
+
+
+def test_large_float32_population_specialises_by_itself(Population, torch, monkeypatch):
+    """specialise=None (the default): a float32 population of AUTO_SPECIALISE_MIN_DRONES or more compiles and
+    registers the unrolled kernels of a spec the library does not ship; a smaller one, a float64 one, and any
+    with LD_SPECIALISE=0 do not; a failing compile leaves the run-time-spec kernels in place with a warning."""
+    from learning_drones_amd import _native, build as ld_build
+    from learning_drones_amd.params import MlpSpec
+    import ctypes as C
+    hidden = (11, 7)
+    has = lambda: _native.lib().ld_has_specialisation_f32(C.byref(MlpSpec.from_hidden(hidden))) == 1
+    assert not has()
+    Population(Population.AUTO_SPECIALISE_MIN_DRONES, hidden)             # conftest: LD_SPECIALISE=0
+    assert not has()
+    monkeypatch.setenv("LD_SPECIALISE", "1")
+    Population(64, hidden)
+    Population(Population.AUTO_SPECIALISE_MIN_DRONES, hidden, precision="f64")
+    assert not has()
+    with monkeypatch.context() as m:                                      # hipcc "fails": warning, generic kernels
+        m.setattr(ld_build, "build_specialisation", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("no compiler")))
+        with pytest.warns(RuntimeWarning, match="no run-time specialisation"):
+            pop = Population(Population.AUTO_SPECIALISE_MIN_DRONES, hidden)
+        assert not has() and pop.rollout_geometry(100)["steps_per_launch"] == 1
+        with pytest.raises(RuntimeError):
+            Population(Population.AUTO_SPECIALISE_MIN_DRONES, hidden, specialise=True)
+    pop = Population(Population.AUTO_SPECIALISE_MIN_DRONES, hidden)
+    assert has() and pop.rollout_geometry(100)["steps_per_launch"] == 64 and pop.has_resident_engine()

@@ -52,7 +52,7 @@ for key, cs in agg.items():
              salu_per_wave=d["SQ_INSTS_SALU"] / d["SQ_WAVES"])
     out[key] = d
 json.dump({"round": 2, "command": "rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
-           "note": "per-dispatch means over the dispatches within 20 % of the kernel's largest SQ_WAVE_CYCLES (full live-population launches: the bench also flies random-genome populations whose launches are mostly frozen); SQ_* cycle counters are quad-cycles summed over waves (MI355X_MICROARCH.md); fly_split L=4: 16 timesteps of a 16 384-drone tile per launch, L=8: of the 8 192-drone shard, L=1: one timestep of 65 536 drones; fly_resident: a whole 2 000-step episode of 65 536 drones per launch",
+           "note": "per-dispatch means over the dispatches within 20 % of the kernel's largest SQ_WAVE_CYCLES (full live-population launches: the bench also flies random-genome populations whose launches are mostly frozen); SQ_* cycle counters are quad-cycles summed over waves (MI355X_MICROARCH.md); fly_split L=4: 64 timesteps of a 16 384-drone tile per launch, L=8: 64 timesteps of the 8 192-drone shard (two workgroups of 8 wavefronts per block), L=2: 64 timesteps of all 65 536 drones, L=1: one timestep of 65 536 drones; fly_resident: a whole 2 000-step episode of 65 536 drones per launch",
            "kernels": out}, open("profiles/r02_sq_counters.json", "w"), indent=1)
 
 # ---- kernel stats

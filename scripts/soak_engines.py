@@ -1,6 +1,6 @@
 """Soak test: every engine and launch geometry against the run-time-spec step kernel on randomly drawn
 populations (sizes, layer specs, episode lengths, coin tables with and without the respawn rule, wall
-boxes, wind, initial states): the default rollout (16 timesteps per launch, wavefronts per block chosen
+boxes, wind, initial states): the default rollout (64 timesteps per launch, wavefronts per block chosen
 from n), a random (wavefronts per block, timesteps per launch) pair, and the work-queue resident engine.
 Any difference in state, bookkeeping or records is an error.  usage: soak_engines.py [rounds]"""
 import sys

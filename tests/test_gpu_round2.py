@@ -499,3 +499,15 @@ def test_large_float32_population_specialises_by_itself(Population, torch, monke
             Population(Population.AUTO_SPECIALISE_MIN_DRONES, hidden, specialise=True)
     pop = Population(Population.AUTO_SPECIALISE_MIN_DRONES, hidden)
     assert has() and pop.rollout_geometry(100)["steps_per_launch"] == 64 and pop.has_resident_engine()
+
+
+def test_short_soak_of_engines_and_geometries():
+    """scripts/soak_engines.py (random sizes, layer specs, episode lengths, coin tables, walls, wind; every engine and a
+    random launch geometry against the run-time-spec kernel) for a dozen rounds: no mismatch.  The long runs (120
+    rounds) are done by hand; this keeps the script and the property alive in the suite."""
+    import subprocess, sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(repo / "scripts" / "soak_engines.py"), "12"], cwd=repo, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "mismatches: 0" in out.stdout and out.stdout.count(" ok") >= 12, out.stdout[-2000:]

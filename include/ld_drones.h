@@ -228,8 +228,9 @@ int ld_fly_step_f64(const ld_sim_params *sim, const ld_episode_params *ep, const
                     const double *coins, const double *walls, const double *genomes,
                     double *fstate, int32_t *istate, int64_t n, void *stream);
 
-/* `n_steps` iterations of that loop body in ONE launch (float32, layer specs with an unrolled
- * specialisation; others return LD_ERR_SPEC), with the launch geometry made explicit: the 64 drones
+/* `n_steps` iterations of that loop body in ONE launch, with the launch geometry made explicit (float32 layer
+ * specs with an unrolled specialisation; a run-time layer spec has one geometry, one wavefront per block:
+ * waves_per_block 0 or 1, anything else returns LD_ERR_SPEC; ld_fly_steps_f64 is that kernel too): the 64 drones
  * of a genome block are served by `waves_per_block` wavefronts (1, 2, 4, 8: one workgroup of that many;
  * 16, 32: two / four workgroups of 8, each flying 32 / 16 of the block's drones; nets wider than 512
  * gene words: 8, 16 = two / four workgroups of 4, 32 not available; 0 = chosen from n, the spec and
@@ -247,6 +248,9 @@ int ld_fly_steps_f32(const ld_sim_params *sim, const ld_episode_params *ep, cons
                      const double *coins, const double *walls, const float *genomes,
                      float *fstate, int32_t *istate, int64_t n, int32_t n_steps, int32_t waves_per_block,
                      void *stream);
+int ld_fly_steps_f64(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
+                     const double *coins, const double *walls, const double *genomes,
+                     double *fstate, int32_t *istate, int64_t n, int32_t n_steps, void *stream);
 
 /* The tail of fly() (flight/__init__.py:83-87,97-99): distance penalty -100*int(d) to the
  * current coin and the result record, for every drone (crashed ones kept the position they

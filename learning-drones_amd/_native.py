@@ -22,7 +22,7 @@ EXPORTS = (
     "ld_genome_words",
     "ld_genomes_pack_f32", "ld_genomes_unpack_f32", "ld_genomes_pack_f64", "ld_genomes_unpack_f64",
     "ld_population_reset_f32", "ld_population_reset_f64", "ld_measure_f32", "ld_measure_f64",
-    "ld_mlp_forward_f32", "ld_mlp_forward_f64", "ld_fly_step_f32", "ld_fly_step_f64",
+    "ld_mlp_forward_f32", "ld_mlp_forward_f64", "ld_fly_step_f32", "ld_fly_step_f64", "ld_fly_steps_f64",
     "ld_fly_finalize_f32", "ld_fly_finalize_f64", "ld_fly_rollout_f32", "ld_fly_rollout_f64",
     "ld_ga_select", "ld_ga_breed_f32", "ld_ga_breed_f64", "ld_pid_episode_f32", "ld_pid_episode_f64",
     "ld_fly_rollout_resident_f32", "ld_debug_force_generic", "ld_accelerations_f32", "ld_accelerations_f64",
@@ -97,6 +97,7 @@ def _declare(h: C.CDLL) -> None:
     h.ld_fly_rollout_resident_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]
     h.ld_fly_rollout_resident_f64.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]
     h.ld_fly_steps_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, i64, i32, i32, vp]
+    h.ld_fly_steps_f64.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, i64, i32, vp]
     h.ld_fly_rollout_steps_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i64, vp]
     h.ld_accelerations_f32.argtypes = [sim, vp, vp, vp, vp, i64, vp]
     h.ld_accelerations_f64.argtypes = [sim, vp, vp, vp, vp, i64, vp]

@@ -91,19 +91,19 @@ template <int... H> bool spec_is(const ld_mlp_spec& s) { return ld::NetShape<H..
 template <typename Real, bool Faithful>
 int dispatch_fly_step(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,
                       const double* coins, const double* walls, const Real* genomes, Real* fstate,
-                      int32_t* istate, int64_t n, hipStream_t stream)
+                      int32_t* istate, int64_t n, int32_t n_steps, hipStream_t stream)
 {
     if constexpr (sizeof(Real) == 8) {
         if (!g_force_generic.load(std::memory_order_relaxed)) {
 #define X(TAG, ...)                                                                                          \
             if (spec_is<__VA_ARGS__>(*spec))                                                                 \
-                return ld_u_fly_f64_##TAG(sim, ep, spec, coins, walls, genomes, fstate, istate, n, stream);
+                return ld_u_fly_f64_##TAG(sim, ep, spec, coins, walls, genomes, fstate, istate, n, n_steps, stream);
             LD_FOR_EACH_UNROLLED(X)
 #undef X
         }
     }
     return launch_fly_step<Real, Faithful, ld::GenericNet<Real, !Faithful>>(sim, ep, spec, coins, walls, genomes, fstate,
-                                                                           istate, n, stream);
+                                                                           istate, n, n_steps, stream);
 }
 
 template <typename Real, bool Fma>
@@ -199,19 +199,22 @@ int check_fly_args(const ld_sim_params* sim, const ld_episode_params* ep, const 
     return LD_OK;
 }
 
+// n_steps iterations of fly()'s loop body in one launch: the multi-wavefront kernels for float32 specs with an
+// unrolled specialisation, the one-wavefront-per-block kernel (float64; run-time layer specs) otherwise.
 template <typename Real, bool Faithful>
 int fly_step_impl(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,
                   const double* coins, const double* walls, const Real* genomes, Real* fstate,
-                  int32_t* istate, int64_t n, void* stream)
+                  int32_t* istate, int64_t n, int32_t n_steps, void* stream)
 {
+    if (n_steps < 0) return LD_ERR_SIZE;
     const int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
-    if (rc || n == 0) return rc;                    // an empty population is a no-op
+    if (rc || n == 0 || n_steps == 0) return rc;    // an empty population is a no-op
     if constexpr (sizeof(Real) == 4) {
         if (has_unrolled(*spec))
-            return dispatch_split_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, 0, n, 1, 0,
+            return dispatch_split_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, 0, n, n_steps, 0,
                                       static_cast<hipStream_t>(stream));
     }
-    return dispatch_fly_step<Real, Faithful>(sim, ep, spec, coins, walls, genomes, fstate, istate, n,
+    return dispatch_fly_step<Real, Faithful>(sim, ep, spec, coins, walls, genomes, fstate, istate, n, n_steps,
                                              static_cast<hipStream_t>(stream));
 }
 
@@ -263,8 +266,17 @@ int rollout_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, con
     if (waves != 0 && waves != 1 && waves != 2 && waves != 4 && waves != 8 && waves != 16 && waves != 32) return LD_ERR_SIZE;
     int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
     if (rc || n == 0) return rc;
-    if (!has_unrolled(*spec)) return LD_ERR_SPEC;
     if (steps_per_launch == 0) steps_per_launch = auto_steps_per_launch();
+    if (!has_unrolled(*spec)) {                     // run-time layer spec: one wavefront per block, whole-population launches
+        if (waves > 1) return LD_ERR_SPEC;
+        for (int32_t t = 0; t < timesteps; t += steps_per_launch) {
+            rc = dispatch_fly_step<float, false>(sim, ep, spec, coins, walls, genomes, fstate, istate, n,
+                                                 timesteps - t < steps_per_launch ? timesteps - t : steps_per_launch,
+                                                 static_cast<hipStream_t>(stream));
+            if (rc) return rc;
+        }
+        return finalize_impl<float>(ep, coins, fstate, istate, records, nullptr, n, stream);
+    }
     if (tile_drones == 0) tile_drones = auto_tile_drones(spec, n, steps_per_launch);
     for (int64_t begin = 0; begin < n; begin += tile_drones) {              // a tile's whole episode, then the next tile
         const int64_t end = begin + tile_drones < n ? begin + tile_drones : n;
@@ -288,8 +300,15 @@ int rollout_impl(const ld_sim_params* sim, const ld_episode_params* ep, const ld
         if (spec && check_spec(spec) == LD_OK && has_unrolled(*spec))
             return rollout_steps_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, records, n, timesteps, 0, 0, 0, stream);
     }
-    for (int32_t t = 0; t < timesteps; ++t) {
-        const int rc = fly_step_impl<Real, Faithful>(sim, ep, spec, coins, walls, genomes, fstate, istate, n, stream);
+    // float64, and float32 layer specs without a specialisation: the one-wavefront-per-block kernel, the same
+    // number of timesteps per launch (state in registers in between; no tiles: one wavefront per block needs the
+    // whole population to fill the chip)
+    const int32_t per_launch = auto_steps_per_launch();
+    int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
+    if (rc) return rc;
+    for (int32_t t = 0; t < timesteps; t += per_launch) {
+        rc = fly_step_impl<Real, Faithful>(sim, ep, spec, coins, walls, genomes, fstate, istate, n,
+                                           timesteps - t < per_launch ? timesteps - t : per_launch, stream);
         if (rc) return rc;
     }
     return finalize_impl<Real>(ep, coins, fstate, istate, records, distance_f64, n, stream);
@@ -560,7 +579,11 @@ int ld_fly_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, cons
         return LD_ERR_SIZE;
     const int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
     if (rc || n == 0 || n_steps == 0) return rc;
-    if (!has_unrolled(*spec)) return LD_ERR_SPEC;
+    if (!has_unrolled(*spec)) {                     // run-time layer spec: one wavefront per block is the only geometry
+        if (waves_per_block > 1) return LD_ERR_SPEC;
+        return dispatch_fly_step<float, false>(sim, ep, spec, coins, walls, genomes, fstate, istate, n, n_steps,
+                                               static_cast<hipStream_t>(stream));
+    }
     return dispatch_split_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, 0, n, n_steps, waves_per_block,
                               static_cast<hipStream_t>(stream));
 }
@@ -573,7 +596,7 @@ int ld_fly_rollout_geometry_f32(const ld_mlp_spec* spec, int64_t n, int32_t time
     if (n < 0 || timesteps < 0) return LD_ERR_SIZE;
     if (!steps_per_launch || !waves_per_block || !n_launches || !tile_drones) return LD_ERR_NULL;
     const bool split = has_unrolled(*spec);
-    *steps_per_launch = split ? auto_steps_per_launch() : 1;
+    *steps_per_launch = auto_steps_per_launch();
     *tile_drones = split && n > 0 ? auto_tile_drones(spec, n, *steps_per_launch) : n;
     *waves_per_block = split ? auto_waves_per_block(spec, *tile_drones, *steps_per_launch) : 1;
     const int64_t tiles = *tile_drones > 0 ? (n + *tile_drones - 1) / *tile_drones : 1;
@@ -712,10 +735,14 @@ int ld_mlp_forward_f64(const ld_mlp_spec* spec, const double* genomes, const dou
 
 int ld_fly_step_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec, const double* coins,
                     const double* walls, const float* genomes, float* fstate, int32_t* istate, int64_t n, void* stream)
-{ return fly_step_impl<float, false>(sim, ep, spec, coins, walls, genomes, fstate, istate, n, stream); }
+{ return fly_step_impl<float, false>(sim, ep, spec, coins, walls, genomes, fstate, istate, n, 1, stream); }
 int ld_fly_step_f64(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec, const double* coins,
                     const double* walls, const double* genomes, double* fstate, int32_t* istate, int64_t n, void* stream)
-{ return fly_step_impl<double, true>(sim, ep, spec, coins, walls, genomes, fstate, istate, n, stream); }
+{ return fly_step_impl<double, true>(sim, ep, spec, coins, walls, genomes, fstate, istate, n, 1, stream); }
+int ld_fly_steps_f64(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec, const double* coins,
+                     const double* walls, const double* genomes, double* fstate, int32_t* istate, int64_t n, int32_t n_steps,
+                     void* stream)
+{ return fly_step_impl<double, true>(sim, ep, spec, coins, walls, genomes, fstate, istate, n, n_steps, stream); }
 
 int ld_fly_finalize_f32(const ld_episode_params* ep, const double* coins, const float* fstate, int32_t* istate,
                         ld_fitness_record* records, int64_t n, void* stream)

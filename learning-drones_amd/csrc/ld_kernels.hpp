@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(Net::kBlock)
 fly_step_kernel(const SimT<Real> sim, const EpT<Real> ep, const ld_mlp_spec spec,
                 const double* __restrict__ coins, const double* __restrict__ walls,
                 const GeneWord<Real>* __restrict__ genomes, Real* __restrict__ fstate,
-                int32_t* __restrict__ istate, const int64_t n)
+                int32_t* __restrict__ istate, const int64_t n, const int32_t n_steps)
 {
     __shared__ Tables<Real> tab;
     __shared__ typename Net::Lds net_lds;
@@ -139,37 +139,53 @@ fly_step_kernel(const SimT<Real> sim, const EpT<Real> ep, const ld_mlp_spec spec
     stage_tables<Real>(tab, ep, coins, walls);
     __syncthreads();
 
-    const bool dead = (status & 1) || !valid;                 // crashed earlier: frozen
-    if (__all(dead)) return;                                  // whole wavefront frozen: only the ring's first words were requested
+    const bool frozen = (status & 1) || !valid;               // crashed earlier (or a tail lane): nothing to store
+    bool dead = frozen;
+    int32_t flight_time = status >> 1;
+    // n_steps iterations of the loop body with the drone in registers (n_steps = 1: the literal contract, one
+    // launch per timestep).  A lane that crashes freezes: the following iterations leave it alone.
+    for (int32_t t = 0; t < n_steps; ++t) {
+        if (__all(dead)) break;                               // whole wavefront frozen: only the ring's first words were requested
+        if (t > 0) Net::prefetch(spec, genomes, lane_offset, ring);
 
-    const int32_t flight_time = (status >> 1) + 1;            // flight/__init__.py:45
-    reward += ep.reward_time;                                 // :41-44
-    Real c[LD_COIN_STRIDE];
-    if (current_coin<Real>(ep, tab.coins, ncoll, c)) {        // :47-52, test against the pre-step position
-        if (coin_distance<Real>(c, d.s) < c[3]) {
-            reward += (int32_t)c[4];
-            ncoll += 1;
+        int32_t r = reward + ep.reward_time;                  // flight/__init__.py:41-44
+        int32_t nc = ncoll;
+        Real c[LD_COIN_STRIDE];
+        if (current_coin<Real>(ep, tab.coins, nc, c)) {       // :47-52, test against the pre-step position
+            if (coin_distance<Real>(c, d.s) < c[3]) {
+                r += (int32_t)c[4];
+                nc += 1;
+            }
         }
-    }
-    const bool crashed = measure<Real, Faithful>(sim, ep, tab.walls, d, reward);   // :79
+        DroneRegs<Real> e = d;
+        const bool crashed = measure<Real, Faithful>(sim, ep, tab.walls, e, r);   // :79
 
-    // :89 controller on the post-step state; its output acts at the next step
-    current_coin<Real>(ep, tab.coins, ncoll, c);
-    Real x[LD_N_INPUTS], y[LD_N_OUTPUTS];
+        // :89 controller on the post-step state; its output acts at the next step
+        current_coin<Real>(ep, tab.coins, nc, c);
+        Real x[LD_N_INPUTS], y[LD_N_OUTPUTS];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) x[k] = d.s[k];
+        for (int k = 0; k < 12; ++k) x[k] = e.s[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) x[12 + k] = c[k];
-    Net::forward(spec, net_lds, genomes, lane_offset, ring, x, y);
-    // a select, not a branch: under `if (!crashed)` the compiler sinks the output layer and its
-    // gene loads into the conditional block, past the pinned pipeline
+        for (int k = 0; k < 3; ++k) x[12 + k] = c[k];
+        Net::forward(spec, net_lds, genomes, lane_offset, ring, x, y);
+        // selects, not branches: under `if (!crashed)` the compiler sinks the output layer and its
+        // gene loads into the conditional block, past the pinned pipeline
 #pragma unroll
-    for (int k = 0; k < LD_N_OUTPUTS; ++k) d.u[k] = crashed ? d.u[k] : y[k];
-    if (!dead) {
+        for (int k = 0; k < 12; ++k) d.s[k] = dead ? d.s[k] : e.s[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d.acc[k] = dead ? d.acc[k] : e.acc[k];
+#pragma unroll
+        for (int k = 0; k < LD_N_OUTPUTS; ++k) d.u[k] = (dead || crashed) ? d.u[k] : y[k];
+        reward = dead ? reward : r;
+        ncoll = dead ? ncoll : nc;
+        flight_time += dead ? 0 : 1;                          // :45
+        dead = dead || crashed;
+    }
+    if (!frozen) {
         store_drone<Real>(fstate, n, i, d);
         istate[(int64_t)LD_I_REWARD * n + i] = reward;
         istate[(int64_t)LD_I_COINS * n + i] = ncoll;
-        istate[(int64_t)LD_I_STATUS * n + i] = 2 * flight_time + (crashed ? 1 : 0);
+        istate[(int64_t)LD_I_STATUS * n + i] = 2 * flight_time + ((dead && valid) ? 1 : 0);
     }
 }
 
@@ -334,11 +350,11 @@ inline unsigned blocks_for(int64_t n, int block) { return (unsigned)((n + block 
 template <typename Real, bool Faithful, typename Net>
 int launch_fly_step(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,
                     const double* coins, const double* walls, const Real* genomes, Real* fstate,
-                    int32_t* istate, int64_t n, hipStream_t stream)
+                    int32_t* istate, int64_t n, int32_t n_steps, hipStream_t stream)
 {
     hipLaunchKernelGGL((fly_step_kernel<Real, Faithful, Net>), dim3(blocks_for(n, Net::kBlock)), dim3(Net::kBlock),
                        0, stream, make_sim<Real>(*sim), make_ep<Real>(*ep), *spec, coins, walls,
-                       reinterpret_cast<const GeneWord<Real>*>(genomes), fstate, istate, n);
+                       reinterpret_cast<const GeneWord<Real>*>(genomes), fstate, istate, n, n_steps);
     return check_launch("fly_step_kernel");
 }
 
@@ -361,7 +377,7 @@ int launch_mlp(const ld_mlp_spec* spec, const Real* genomes, const Real* inputs,
 
 #define LD_DECLARE_UNROLLED(TAG, ...)                                                                            \
     int ld_u_fly_f64_##TAG(const ld_sim_params*, const ld_episode_params*, const ld_mlp_spec*, const double*,    \
-                           const double*, const double*, double*, int32_t*, int64_t, hipStream_t);               \
+                           const double*, const double*, double*, int32_t*, int64_t, int32_t, hipStream_t);      \
     int ld_u_mlp_f32_##TAG(const ld_mlp_spec*, const float*, const float*, float*, int64_t, hipStream_t);        \
     int ld_u_mlp_f64_##TAG(const ld_mlp_spec*, const double*, const double*, double*, int64_t, hipStream_t);
 LD_FOR_EACH_UNROLLED(LD_DECLARE_UNROLLED)

@@ -234,16 +234,23 @@ class Population:
                                               self.n, self._stream()), "ld_fly_step")
 
     def steps(self, n_steps: int, waves_per_block: int = 0) -> None:
-        """`n_steps` iterations of fly()'s loop in ONE launch (ld_fly_steps_f32: float32, unrolled layer
-        specs), the 64 drones of a genome block served by `waves_per_block` wavefronts (0 = chosen from n).
-        Bit-identical to n_steps calls of step()."""
-        if self.precision != "f32":
-            raise ValueError("steps() is float32 (the float64 kernels take one launch per timestep)")
-        _native.check(_native.lib().ld_fly_steps_f32(C.byref(self.sim), C.byref(self.episode), C.byref(self.spec),
-                                                     self._ptr(self.coins_dev), self._ptr(self.walls_dev),
-                                                     self._ptr(self.genomes), self._ptr(self.fstate), self._ptr(self.istate),
-                                                     self.n, int(n_steps), int(waves_per_block), self._stream()),
-                      "ld_fly_steps_f32")
+        """`n_steps` iterations of fly()'s loop in ONE launch (ld_fly_steps_f32 / _f64), the drone state in
+        registers in between.  float32 layer specs with an unrolled specialisation: the 64 drones of a genome block
+        served by `waves_per_block` wavefronts (0 = chosen from n); float64 and run-time layer specs: one wavefront
+        per block (waves_per_block 0 or 1).  Bit-identical to n_steps calls of step()."""
+        if self.precision == "f32":
+            rc = _native.lib().ld_fly_steps_f32(C.byref(self.sim), C.byref(self.episode), C.byref(self.spec),
+                                                self._ptr(self.coins_dev), self._ptr(self.walls_dev),
+                                                self._ptr(self.genomes), self._ptr(self.fstate), self._ptr(self.istate),
+                                                self.n, int(n_steps), int(waves_per_block), self._stream())
+        else:
+            if waves_per_block not in (0, 1):
+                raise ValueError("the float64 kernels have one geometry: one wavefront per genome block")
+            rc = _native.lib().ld_fly_steps_f64(C.byref(self.sim), C.byref(self.episode), C.byref(self.spec),
+                                                self._ptr(self.coins_dev), self._ptr(self.walls_dev),
+                                                self._ptr(self.genomes), self._ptr(self.fstate), self._ptr(self.istate),
+                                                self.n, int(n_steps), self._stream())
+        _native.check(rc, "ld_fly_steps")
 
     def finalize(self) -> None:
         """Tail of fly(): distance penalty + result records (flight/__init__.py:83-87,97-99)."""
@@ -325,10 +332,11 @@ class Population:
         """What fly(timesteps) (step engine, default geometry) launches: loop iterations per launch,
         wavefronts per genome block, fused-step launches per episode (ld_fly_rollout_geometry_f32)."""
         k, w, m, tile = C.c_int32(1), C.c_int32(1), C.c_int32(int(timesteps)), C.c_int64(self.n)
-        if self.precision == "f32":
-            _native.check(_native.lib().ld_fly_rollout_geometry_f32(C.byref(self.spec), self.n, int(timesteps), C.byref(k),
-                                                                    C.byref(w), C.byref(m), C.byref(tile)),
-                          "ld_fly_rollout_geometry_f32")
+        _native.check(_native.lib().ld_fly_rollout_geometry_f32(C.byref(self.spec), self.n, int(timesteps), C.byref(k),
+                                                                C.byref(w), C.byref(m), C.byref(tile)),
+                      "ld_fly_rollout_geometry_f32")
+        if self.precision == "f64":             # the same timesteps per launch, one wavefront per block, no tiles
+            return {"steps_per_launch": k.value, "waves_per_block": 1, "launches": -(-int(timesteps) // k.value), "tile_drones": self.n}
         return {"steps_per_launch": k.value, "waves_per_block": w.value, "launches": m.value, "tile_drones": tile.value}
 
     def auto_waves_per_block(self, drones: int, steps_per_launch: int) -> int:

@@ -494,11 +494,11 @@ def test_large_float32_population_specialises_by_itself(Population, torch, monke
         m.setattr(ld_build, "build_specialisation", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("no compiler")))
         with pytest.warns(RuntimeWarning, match="no run-time specialisation"):
             pop = Population(Population.AUTO_SPECIALISE_MIN_DRONES, hidden)
-        assert not has() and pop.rollout_geometry(100)["steps_per_launch"] == 1
+        assert not has() and pop.rollout_geometry(100)["waves_per_block"] == 1
         with pytest.raises(RuntimeError):
             Population(Population.AUTO_SPECIALISE_MIN_DRONES, hidden, specialise=True)
     pop = Population(Population.AUTO_SPECIALISE_MIN_DRONES, hidden)
-    assert has() and pop.rollout_geometry(100)["steps_per_launch"] == 64 and pop.has_resident_engine()
+    assert has() and pop.rollout_geometry(100)["waves_per_block"] > 1 and pop.has_resident_engine()
 
 
 def test_short_soak_of_engines_and_geometries():
@@ -511,3 +511,55 @@ def test_short_soak_of_engines_and_geometries():
     out = subprocess.run([sys.executable, str(repo / "scripts" / "soak_engines.py"), "12"], cwd=repo, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "mismatches: 0" in out.stdout and out.stdout.count(" ok") >= 12, out.stdout[-2000:]
+
+
+@pytest.mark.parametrize("precision,hidden,force_generic", [("f64", (32, 32), False), ("f64", (10, 10), True), ("f64", (9, 13, 11), False),
+                                                            ("f32", (13, 9), False), ("f32", (32, 32), True)])
+def test_one_wavefront_kernels_fly_several_timesteps_per_launch(Population, torch, generic_kernels, precision, hidden, force_generic):
+    """ld_fly_steps_f64 / ld_fly_steps_f32 on a run-time layer spec: the one-wavefront-per-block kernel (float64
+    unrolled and run-time-spec, float32 run-time-spec) with the timestep loop inside the launch equals one launch
+    per timestep bit for bit, and fly() (64 timesteps per launch) equals that plus finalize."""
+    from test_gpu_parity import _mixed_genomes
+    n, T = 150, 330
+    spec, genes, cls = _mixed_genomes(hidden, n, seed=23)
+    walls = np.array([[3.0, 3.0, 8.0, 4.5, 7.0, 12.0]])
+    generic_kernels(force_generic)
+
+    def fresh():
+        pop = Population(n, hidden, precision=precision, walls=walls, coins=coin_chain_reference(2), specialise=False)
+        pop.set_genomes(genes)
+        return pop
+
+    ref = fresh()
+    for _ in range(T):
+        ref.step()
+    crashed = (ref.istate[2] & 1).bool()
+    assert crashed.any() and not crashed.all()
+    for k in (1, 7, 64, T):
+        pop = fresh()
+        done = 0
+        while done < T:
+            pop.steps(min(k, T - done))
+            done += min(k, T - done)
+        assert torch.equal(pop.fstate, ref.fstate) and torch.equal(pop.istate, ref.istate), k
+    geo = fresh().rollout_geometry(T)
+    assert (geo["steps_per_launch"], geo["waves_per_block"], geo["launches"]) == (64, 1, 6)
+    ref.finalize()
+    pop = fresh()
+    pop.fly(T)
+    assert torch.equal(pop.records, ref.records) and torch.equal(pop.fstate, ref.fstate)
+    assert precision == "f32" or torch.equal(pop.distance, ref.distance)
+    if precision == "f32":
+        pop = fresh()
+        pop.fly(T, steps_per_launch=50)                                # explicit geometry on a run-time layer spec
+        assert torch.equal(pop.records, ref.records)
+        with pytest.raises(_native_error()):
+            fresh().steps(3, 4)                                        # one wavefront per block is its only geometry
+    else:
+        with pytest.raises(ValueError):
+            fresh().steps(3, 4)
+
+
+def _native_error():
+    from learning_drones_amd._native import LdError
+    return LdError

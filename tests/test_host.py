@@ -173,7 +173,7 @@ def test_argument_validation_without_gpu(lib):
     assert steps(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, 8, 4, 3, None) == SIZE      # waves not 0/1/2/4/8/16/32
     assert steps(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, 0, 4, 8, None) == OK
     assert steps(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, odd, fake, fake, 8, 4, 8, None) == ALIGN
-    assert steps(C.byref(sim), C.byref(ep), C.byref(MlpSpec.from_hidden((12,))), fake, None, fake, fake, fake, 8, 4, 0, None) == SPEC
+    assert steps(C.byref(sim), C.byref(ep), C.byref(MlpSpec.from_hidden((12,))), fake, None, fake, fake, fake, 8, 4, 4, None) == SPEC   # run-time spec: one wavefront per block only
     ro = lib.ld_fly_rollout_steps_f32
     assert ro(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, fake, 8, 10, -1, 0, 0, None) == SIZE
     assert ro(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, fake, 8, 10, 0, 0, 100, None) == SIZE   # tile not a multiple of 64
@@ -186,7 +186,7 @@ def test_argument_validation_without_gpu(lib):
     assert geo((32, 32), 32768, 4000) == (OK, 64, 4, 126, 16384)           # config 4 shard: 223 MB -> two tiles
     assert geo((32, 32), 16384, 2000) == (OK, 64, 4, 32, 16384)
     assert geo((64, 64, 64), 131072, 4000) == (OK, 64, 1, 63, 131072)     # 38 KB of genes per drone: a tile could not fill the chip
-    assert geo((64, 64, 64), 8192, 100) == (OK, 64, 8, 2, 8192) and geo((12,), 1000, 50) == (OK, 1, 1, 50, 1000)
+    assert geo((64, 64, 64), 8192, 100) == (OK, 64, 8, 2, 8192) and geo((12,), 1000, 50) == (OK, 64, 1, 1, 1000)   # run-time spec: one wavefront per block, 64 timesteps per launch
     assert geo((10, 10), 65536, 2000) == (OK, 64, 2, 32, 65536)           # 82 MB: fits as it is
     assert geo((10, 10), 1048576, 100)[4] == 65536
     assert lib.ld_fly_rollout_geometry_f32(C.byref(spec), 8, 8, None, None, None, None) == NULL

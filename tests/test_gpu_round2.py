@@ -563,3 +563,55 @@ def test_one_wavefront_kernels_fly_several_timesteps_per_launch(Population, torc
 def _native_error():
     from learning_drones_amd._native import LdError
     return LdError
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    """bench.py on a small workload: exactly one JSON line on stdout carrying the driver's contract fields, the
+    roofline object (live launch duration from HIP events) and, at N = 1, the cpu_baseline object."""
+    import json, subprocess, sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--drones", "4096",
+                          "--timesteps", "200"], cwd=repo, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f32" and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 4096 * 200 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["launch_us"] > 0 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["one_thread"]["cores"] == 1
+    assert d["ranks_seen"] == [0] and d["records"]["rows"] == 4096
+
+
+def test_bench_two_ranks_on_one_gpu_rehearses_the_multi_gpu_flow():
+    """bench.py --gpus 2 launched the way the driver launches it, two ranks sharing this GPU with gloo carrying the
+    collectives (RCCL refuses two ranks on one device): the N > 1 control flow -- sharding, the records all-gather in
+    every episode, max-over-ranks timing, the strong-scaling case, the generation step with its parent exchange --
+    runs to the one JSON line, which proves both ranks were seen."""
+    import json, socket, subprocess, sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(repo / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--drones", "8192",
+           "--timesteps", "150", "--backend", "gloo"]
+    out = subprocess.run(cmd, cwd=repo, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == [0, 1] and d["records"]["rows"] == 2 * 8192 and d["scaling"] == "weak"
+    s = d["strong_scaling"]
+    assert s["scaling"] == "strong" and s["population"] == 8192 and s["drones_per_gpu"] == 4096 and s["records"]["rows"] == 8192
+    assert d["generation"]["error"] is None and d["generations_per_s"] > 0
+    assert "cpu_baseline" not in d                                        # rank 0 at N = 1 only

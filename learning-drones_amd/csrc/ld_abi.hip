@@ -133,15 +133,43 @@ int dispatch_mlp(const ld_mlp_spec* spec, const Real* genomes, const Real* input
 // workgroup per block (8 192 drones = 128 blocks on 256 CUs, each CU pulling its block's genes at the ~50 GB/s
 // one CU can draw from L2 / Infinity Cache), so a block is split over 2 or 4 workgroups of 8 wavefronts (of 4 for
 // the nets wider than 512 gene words): 8 192 x 32-32 8.65 -> 6.74 us per timestep, 4 096: 7.64 -> 5.74.
+// A split over L wavefronts is "even" when every hidden layer gives each wavefront the same number of rows, and at
+// least two.  For some of the others (8-10, 10-10, 13-7 from L = 4, 8-8 at L = 8 -- not 20-20 at L = 8, and none at
+// L = 2) the compiler produces kernels that keep the gene ring in scratch (10-10 at 65 536 drones: 9.4 us per
+// timestep at L = 2, 35.6 at L = 4).  Which ones is not predictable from the shape, so beyond two wavefronts per
+// workgroup the policy below picks even splits only (an explicit waves_per_block still may pick any: the results
+// are the same, the speed is not).
+bool even_split(const ld_mlp_spec* spec, int waves_per_workgroup)
+{
+    if (waves_per_workgroup <= 2) return true;
+    for (int i = 0; i < spec->n_hidden; ++i)
+        if (spec->hidden[i] % waves_per_workgroup != 0 || spec->hidden[i] / waves_per_workgroup < 2) return false;
+    return true;
+}
+
 int auto_waves_per_block(const ld_mlp_spec* spec, int64_t n, int32_t n_steps)
 {
     const int64_t blocks = (n + 63) / 64;
     const int64_t target = n_steps > 1 ? 2048 : 1024;
+    const int64_t words = ld_mlp_words_per_drone(spec);
+    const bool wide = words > 512;
+    int most = 4;                                                // the most wavefronts per workgroup with an even split
+    while (most > 1 && !even_split(spec, most)) most /= 2;
     int waves = 1;
-    while (waves * 2 <= 4 && blocks * waves * 2 <= target) waves *= 2;
-    if (waves < 4 || blocks * 4 >= 1024) return waves;          // the chip is full with one workgroup of <= 4 per block
-    const bool wide = ld_mlp_words_per_drone(spec) > 512;
+    while (waves * 2 <= most && blocks * waves * 2 <= target) waves *= 2;
+    if (blocks * 4 >= 1024) {
+        // The chip is full at one workgroup of <= 4 wavefronts per block.  A launch of several timesteps still gains
+        // from more wavefronts per block than "two per SIMD" asks for (scripts/ab_large.py, us per timestep at
+        // 1 / 2 / 4 / 8: 32-32 x 65 536 65.6 / 63.1 / 60.2 / 60.6, 16-16 x 131 072 44.0 / 41.8 / 41.5 / 38.1,
+        // 64 x 65 536 46.4 / 45.5 / 43.2 / 43.4, 32-32-32 x 65 536 107 / 103 / 99 / 94, 8-8 x 131 072 16.4 / 15.5 / 14.4 / 41.7)
+        if (n_steps < 4) return waves;
+        if (wide) return most == 4 ? 8 : waves;                  // two workgroups of 4
+        if (words > 100 && words <= 256 && even_split(spec, 8)) return 8;
+        return most;
+    }
+    if (waves < 4) return waves;
     const int per_group = wide ? 4 : 8;                          // wavefronts per workgroup beyond 4
+    if (!even_split(spec, per_group)) return wide ? waves : 4;
     int groups = 1;                                              // workgroups per block
     const int64_t group_target = wide ? 1024 : target;           // (64-64-64 at 8 192 drones: 51.5 / 43.8 / 59.5 us at 1 / 2 / 4)
     if (n_steps > 1)

@@ -185,9 +185,10 @@ def test_argument_validation_without_gpu(lib):
     assert geo((32, 32), 65536, 2000) == (OK, 64, 4, 128, 16384) and geo((32, 32), 8192, 2000) == (OK, 64, 16, 32, 8192)
     assert geo((32, 32), 32768, 4000) == (OK, 64, 4, 126, 16384)           # config 4 shard: 223 MB -> two tiles
     assert geo((32, 32), 16384, 2000) == (OK, 64, 4, 32, 16384)
-    assert geo((64, 64, 64), 131072, 4000) == (OK, 64, 1, 63, 131072)     # 38 KB of genes per drone: a tile could not fill the chip
+    assert geo((64, 64, 64), 131072, 4000) == (OK, 64, 8, 63, 131072)     # 38 KB of genes per drone: a tile could not fill the chip; two workgroups of 4
     assert geo((64, 64, 64), 8192, 100) == (OK, 64, 8, 2, 8192) and geo((12,), 1000, 50) == (OK, 64, 1, 1, 1000)   # run-time spec: one wavefront per block, 64 timesteps per launch
-    assert geo((10, 10), 65536, 2000) == (OK, 64, 2, 32, 65536)           # 82 MB: fits as it is
+    assert geo((10, 10), 65536, 2000) == (OK, 64, 2, 32, 65536)           # 82 MB: fits as it is; 10 rows split evenly over 2 wavefronts only
+    assert geo((10, 10), 1024, 2000)[2] == 2 and geo((8, 8), 1024, 2000)[2] == 4 and geo((16, 16), 65536, 2000)[2] == 8
     assert geo((10, 10), 1048576, 100)[4] == 65536
     assert lib.ld_fly_rollout_geometry_f32(C.byref(spec), 8, 8, None, None, None, None) == NULL
     for sfx in ("f32", "f64"):
@@ -229,7 +230,7 @@ def test_runtime_specialisation_builds_and_registers(lib):
     k, w, m = C.c_int32(), C.c_int32(), C.c_int32()
     tile = C.c_int64()
     assert lib.ld_fly_rollout_geometry_f32(C.byref(spec), 8192, 2000, C.byref(k), C.byref(w), C.byref(m), C.byref(tile)) == 0
-    assert (k.value, w.value, m.value, tile.value) == (64, 16, 32, 8192)                   # the specialised spec takes the multi-step geometry
+    assert (k.value, w.value, m.value, tile.value) == (64, 2, 32, 8192)                    # the specialised spec takes the multi-step geometry (13 and 7 rows: two wavefronts at most)
     assert lib.ld_debug_force_generic(1) == 0 and lib.ld_has_specialisation_f32(C.byref(spec)) == 0
     assert lib.ld_debug_force_generic(0) == 1
     # the entry points validate like the built-in ones (n == 0 is a no-op, no kernel is launched without a GPU)

@@ -10,6 +10,12 @@ and speed (see csrc/ld_device.hpp, csrc/ld_nets.hpp):
                         oracle's float arithmetic operation for operation
   -fno-slp-vectorize    the SLP vectoriser pairs neighbouring neurons into v_pk_fma_f32 and in doing
                         so regroups the gene loads into bursts, destroying the load pipeline
+  -mllvm -simplifycfg-sink-common=false   (the multi-wavefront step kernels of layer specs with a hidden layer
+                        narrower than 16, shipped or compiled at run time)  the wavefronts of a block run different arms of one switch; SimplifyCFG
+                        sinks their look-alike `ring[i] = load(...)` statements into a common block that
+                        stores through a phi of ring-slot addresses, which keeps the whole gene ring from being
+                        promoted to registers: 10-10, 8-10, 12-12, 13-7 from four wavefronts per block and 8-8
+                        at eight then ran out of scratch, 3-4x slower
 """
 from __future__ import annotations
 
@@ -28,6 +34,20 @@ SOURCES = sorted(CSRC.glob("*.hip"))
 HEADERS = sorted(CSRC.glob("*.hpp")) + sorted(CSRC.glob("*.inc")) + [PKG_DIR.parent / "include" / "ld_drones.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
          "-Wall", "-Wno-unused-function"]
+NO_SINK = ["-mllvm", "-simplifycfg-sink-common=false"]
+
+
+def narrow(hidden) -> bool:
+    """Layer specs with a hidden layer narrower than 16: the ones whose multi-wavefront kernels need NO_SINK (wider ones
+    are clean without it, and 15-16-4 at eight wavefronts per block spills WITH it)."""
+    return min(int(h) for h in hidden) < 16
+
+
+def flags_for(src: Path):
+    if src.name.startswith("ld_split_"):
+        widths = [t for t in src.stem[len("ld_split_"):].split("_") if t.isdigit()]
+        return FLAGS + (NO_SINK if narrow(widths) else [])
+    return FLAGS
 
 
 def hipcc() -> str:
@@ -57,7 +77,7 @@ def _compile(src: Path, verbose: bool) -> Path:
         newest = _newest_input() if deps is None else max([Path(__file__).stat().st_mtime] + [d.stat().st_mtime for d in deps if d.exists()])
         if obj.stat().st_mtime >= max(src.stat().st_mtime, newest) and (deps is None or all(d.exists() for d in deps)):
             return obj
-    cmd = [hipcc(), *FLAGS, "-MD", "-MF", str(obj.with_suffix(".d")), "-c", str(src), "-o", str(obj)]
+    cmd = [hipcc(), *flags_for(src), "-MD", "-MF", str(obj.with_suffix(".d")), "-c", str(src), "-o", str(obj)]
     if verbose:
         print("[learning-drones_amd] " + " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -143,7 +163,7 @@ def build_specialisation(hidden, verbose: bool = False) -> Path:
     mine = JIT_DIR / f"ld_spec_{tag}.{os.getpid()}.hip"
     mine.write_text(text)
     tmp = JIT_DIR / f"libld_spec_{tag}.{os.getpid()}.so"
-    cmd = [hipcc(), *FLAGS, "-shared", str(mine), "-o", str(tmp)]
+    cmd = [hipcc(), *FLAGS, *(NO_SINK if narrow(hidden) else []), "-shared", str(mine), "-o", str(tmp)]
     if verbose:
         print("[learning-drones_amd] " + " ".join(cmd), flush=True)
     try:

@@ -165,7 +165,12 @@ int auto_waves_per_block(const ld_mlp_spec* spec, int64_t n, int32_t n_steps)
         if (n_steps < 4) return waves;
         if (wide) return most == 4 ? 8 : waves;                  // two workgroups of 4
         if (words > 100 && words <= 256 && even_split(spec, 8)) return 8;
-        return most;
+        if (words > 100) return most;
+        // the smallest nets disagree: 8-8 and 15-16-4 gain 7-10 % from 4 wavefronts per block, 10-10, 8-10 and 12-12
+        // lose 25-40 % (65 536 drones, us per timestep at 2 / 4: 10-10 9.5 / 13.4, 12-12 12.5 / 15.7)
+        const bool likes_four = (spec->n_hidden == 2 && spec->hidden[0] == 8 && spec->hidden[1] == 8) ||
+                                (spec->n_hidden == 1 && spec->hidden[0] == 16);
+        return likes_four ? most : (waves < 2 ? waves : 2);
     }
     if (waves < 4) return waves;
     const int per_group = wide ? 4 : 8;                          // wavefronts per workgroup beyond 4

@@ -134,11 +134,11 @@ int dispatch_mlp(const ld_mlp_spec* spec, const Real* genomes, const Real* input
 // one CU can draw from L2 / Infinity Cache), so a block is split over 2 or 4 workgroups of 8 wavefronts (of 4 for
 // the nets wider than 512 gene words): 8 192 x 32-32 8.65 -> 6.74 us per timestep, 4 096: 7.64 -> 5.74.
 // A split over L wavefronts is "even" when every hidden layer gives each wavefront the same number of rows, and at
-// least two.  For some of the others (8-10, 10-10, 13-7 from L = 4, 8-8 at L = 8 -- not 20-20 at L = 8, and none at
-// L = 2) the compiler produces kernels that keep the gene ring in scratch (10-10 at 65 536 drones: 9.4 us per
-// timestep at L = 2, 35.6 at L = 4).  Which ones is not predictable from the shape, so beyond two wavefronts per
-// workgroup the policy below picks even splits only (an explicit waves_per_block still may pick any: the results
-// are the same, the speed is not).
+// least two.  Beyond two wavefronts per workgroup the policy below picks even splits only: the others are the ones
+// whose kernels have ended up with the gene ring in scratch (8-10, 10-10, 12-12, 13-7 from L = 4, 8-8 at L = 8,
+// before their translation units were built with -simplifycfg-sink-common=false, see build.py), and they gain
+// little where they are clean (10-10 x 1 024: 2.4 us per timestep at L = 2, 2.2 at 4).  An explicit waves_per_block
+// may still pick any geometry.
 bool even_split(const ld_mlp_spec* spec, int waves_per_workgroup)
 {
     if (waves_per_workgroup <= 2) return true;

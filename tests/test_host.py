@@ -237,3 +237,15 @@ def test_runtime_specialisation_builds_and_registers(lib):
     sim, ep = SimParams.reference(), EpisodeParams.reference(n_coins=1)
     fake = C.c_void_p(0x1000)
     assert lib.ld_fly_steps_f32(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, 0, 4, 0, None) == 0
+
+
+def test_no_fused_step_kernel_runs_out_of_scratch():
+    """scripts/audit_scratch.py over the built library: no float32 multi-wavefront step kernel keeps more than a
+    handful of bytes per lane in scratch.  (hipcc once turned the narrow layer specs' kernels into ones that held the
+    whole gene ring there, 3-4x slower, without a word at build time; see build.py, NO_SINK.)"""
+    import subprocess, sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(repo / "scripts" / "audit_scratch.py")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "fly_split_kernel<float, false, 4, 1, 32, 32>" in out.stdout and "fly_resident_kernel" in out.stdout

@@ -199,6 +199,7 @@ def main():
             geo.update(steps_per_launch=k, tile_drones=tile, launches=-(-n_local // tile) * -(-T // k))
             # the wavefronts per block the library picks for launches of `tile` drones (or the explicit value)
             geo["waves_per_block"] = args.waves_per_block or pop.local.auto_waves_per_block(tile, k)
+            geo["cached_drones"] = 0                       # an explicit geometry is flown as given: one kernel per launch
 
         def episode():
             pop.local.reset()
@@ -231,7 +232,12 @@ def main():
                 "bytes_per_launch": bytes_per_launch, "launch_us": launch_ms * 1e3,
                 "timesteps_per_launch": geo["steps_per_launch"], "wavefronts_per_block": geo["waves_per_block"],
                 "launches_per_episode": geo["launches"], "drones_per_launch": geo["tile_drones"],
+                "cached_drones_per_launch": geo.get("cached_drones", 0),
                 "tiles": -(-n_local // geo["tile_drones"]),
+                "launch_note": ("a launch here = two concurrent kernels: the first %d drones of the tile by fly_split_kernel<L=8, two "
+                                "workgroups per block, CACHEABLE gene loads> on the library's side stream, the rest by the streaming "
+                                "kernel named above; launch_us = HIP-event time of the episode / launches" % geo.get("cached_drones", 0))
+                               if geo.get("cached_drones", 0) else None,
                 "tiling_note": "a population whose genes exceed the 256 MiB Infinity Cache is flown tile by tile (a tile's whole "
                                "episode, then the next tile): the genes, re-streamed every timestep, then come from HBM once per "
                                "episode and from the cache afterwards, so `achieved` (algorithmic bytes / time) can exceed the HBM "
@@ -347,7 +353,8 @@ def main():
         if (cfg["drones"] == n_local and tuple(cfg["hidden"]) == hidden and cfg["coins"] == args.coins
                 and cfg.get("timesteps_per_launch", 1) == roof["timesteps_per_launch"]
                 and cfg.get("wavefronts_per_block", 1) == roof["wavefronts_per_block"]
-                and cfg.get("drones_per_launch", cfg["drones"]) == roof["drones_per_launch"]):
+                and cfg.get("drones_per_launch", cfg["drones"]) == roof["drones_per_launch"]
+                and cfg.get("cached_drones_per_launch", 0) == roof["cached_drones_per_launch"]):
             roof["traffic"], roof["traffic_source"] = prof["hbm_traffic_bytes_per_launch"], f"profiles/{f.name}"
             if prof.get("launch_us_profiled"):
                 roof["launch_us_profiled"] = prof["launch_us_profiled"]

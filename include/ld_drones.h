@@ -262,10 +262,13 @@ int ld_fly_finalize_f64(const ld_episode_params *ep, const double *coins, const 
                         int64_t n, void *stream);
 
 /* fly(drone, timesteps) for the whole population: the fused-step launches followed by the finalize
- * launch, all enqueued on `stream` from C (no per-step host round trip).  _f64 and the float32 specs
- * without an unrolled specialisation take one launch per timestep; the unrolled float32 specs take
- * ld_fly_rollout_steps_f32's default geometry (several timesteps per launch, state in registers in
- * between; identical results). */
+ * launch, all enqueued from C (no per-step host round trip); everything is ordered on `stream`: work enqueued
+ * on it afterwards sees the finished episode.  64 timesteps per launch, the drone state in registers in between
+ * (identical results).  _f64 and the float32 specs without an unrolled specialisation: one wavefront per genome
+ * block.  The unrolled float32 specs take ld_fly_rollout_steps_f32's default geometry, and for tiles of
+ * >= 16 384 drones the head of each tile is flown concurrently on a side stream the library owns (one per host
+ * thread and device, created at first use, forked from and joined to `stream` by events -- also under stream
+ * capture): see ld_fly_rollout_cached_drones_f32. */
 int ld_fly_rollout_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
                        const double *coins, const double *walls, const float *genomes,
                        float *fstate, int32_t *istate, ld_fitness_record *records,
@@ -297,6 +300,12 @@ int ld_fly_rollout_steps_f32(const ld_sim_params *sim, const ld_episode_params *
 int ld_fly_rollout_geometry_f32(const ld_mlp_spec *spec, int64_t n, int32_t timesteps,
                                 int32_t *steps_per_launch, int32_t *waves_per_block, int32_t *n_launches,
                                 int64_t *tile_drones);
+/* How many drones at the head of each tile ld_fly_rollout_f32 flies with CACHEABLE gene loads, in a second launch
+ * on a side stream of its own that it forks from and joins to `stream` (0 = none: the tile is one launch).  The
+ * L2s (8 x 4 MB) keep a good part of those drones' genes from timestep to timestep while the rest of the tile
+ * streams past them non-temporally; chosen for tiles of >= 16 384 drones of shipped layer specs of up to 512 gene
+ * words (config 3: 4 096 of each 16 384-drone tile; the streaming part then takes waves_per_block = 8). */
+int64_t ld_fly_rollout_cached_drones_f32(const ld_mlp_spec *spec, int64_t n, int32_t timesteps);
 
 /* The wavefronts per genome block ld_fly_steps_f32 takes for waves_per_block = 0 on a launch of n drones and
  * n_steps timesteps (1 for specs without an unrolled specialisation), or a negative ld_status. */

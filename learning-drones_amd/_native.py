@@ -26,7 +26,7 @@ EXPORTS = (
     "ld_fly_finalize_f32", "ld_fly_finalize_f64", "ld_fly_rollout_f32", "ld_fly_rollout_f64",
     "ld_ga_select", "ld_ga_breed_f32", "ld_ga_breed_f64", "ld_pid_episode_f32", "ld_pid_episode_f64",
     "ld_fly_rollout_resident_f32", "ld_debug_force_generic", "ld_accelerations_f32", "ld_accelerations_f64",
-    "ld_fly_steps_f32", "ld_fly_rollout_steps_f32", "ld_fly_rollout_geometry_f32", "ld_fly_steps_resident_f32",
+    "ld_fly_steps_f32", "ld_fly_rollout_steps_f32", "ld_fly_rollout_geometry_f32", "ld_fly_rollout_cached_drones_f32", "ld_fly_steps_resident_f32",
     "ld_fly_rollout_resident_f64", "ld_register_specialisation_f32", "ld_has_specialisation_f32",
     "ld_has_resident_f32", "ld_has_resident_f64", "ld_fly_steps_auto_waves_f32",
 )
@@ -107,6 +107,8 @@ def _declare(h: C.CDLL) -> None:
     h.ld_has_resident_f32.argtypes = [spec]
     h.ld_has_resident_f64.argtypes = [spec]
     h.ld_fly_steps_auto_waves_f32.argtypes = [spec, i64, i32]
+    h.ld_fly_rollout_cached_drones_f32.argtypes = [spec, i64, i32]
+    h.ld_fly_rollout_cached_drones_f32.restype = C.c_int64
     h.ld_fly_steps_resident_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, i64, i32, vp, vp]
     pi32 = C.POINTER(C.c_int32)
     h.ld_fly_rollout_geometry_f32.argtypes = [spec, i64, i32, pi32, pi32, pi32, C.POINTER(C.c_int64)]
@@ -118,7 +120,7 @@ def _declare(h: C.CDLL) -> None:
         getattr(h, f"ld_pid_episode_{sfx}").argtypes = [sim, vp, vp, i32, C.c_double, i32, i32, vp, vp, vp, vp, vp, i64, vp]
     for name in EXPORTS:
         if name not in ("ld_strerror", "ld_last_hip_error", "ld_mlp_param_count", "ld_mlp_words_per_drone",
-                        "ld_genome_words"):
+                        "ld_genome_words", "ld_fly_rollout_cached_drones_f32"):
             getattr(h, name).restype = C.c_int
 
 

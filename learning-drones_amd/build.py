@@ -139,7 +139,7 @@ def build_specialisation(hidden, verbose: bool = False) -> Path:
     JIT_DIR.mkdir(parents=True, exist_ok=True)
     src, lib = JIT_DIR / f"ld_spec_{tag}.hip", JIT_DIR / f"libld_spec_{tag}.so"
     text = (f"// generated by learning_drones_amd.build.build_specialisation({hidden})\n"
-            f"#define LD_TAG jit_{tag}\n#define LD_WIDTHS {widths}\n#define LD_ONLY_F32\n"
+            f"#define LD_TAG jit_{tag}\n#define LD_WIDTHS {widths}\n#define LD_ONLY_F32\n#define LD_NO_CACHED_SPLIT\n"
             f'#include "{CSRC}/ld_unrolled.inc"\n#include "{CSRC}/ld_split.inc"\n#include "{CSRC}/ld_resident.hpp"\n'
             'extern "C" int ld_spec_fly_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, const double* coins, '
             "const double* walls, const float* genomes, float* fstate, int32_t* istate, int64_t n, int64_t begin, int64_t end, "

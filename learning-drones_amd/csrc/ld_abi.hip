@@ -199,6 +199,20 @@ int dispatch_split_f32(const ld_sim_params* sim, const ld_episode_params* ep, co
     return LD_ERR_SPEC;
 }
 
+// The same drones by two workgroups of 8 wavefronts per block with cacheable gene loads (shipped specs of up to 512
+// gene words; LD_ERR_SPEC / LD_ERR_SIZE otherwise).
+int dispatch_split_cached_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec, const double* coins,
+                              const double* walls, const float* genomes, float* fstate, int32_t* istate, int64_t n, int64_t begin,
+                              int64_t end, int32_t n_steps, hipStream_t stream)
+{
+#define X(TAG, ...)                                                                                          \
+    if (spec_is<__VA_ARGS__>(*spec))                                                                         \
+        return ld_u_split_cached_f32_##TAG(sim, ep, coins, walls, genomes, fstate, istate, n, begin, end, n_steps, stream);
+    LD_FOR_EACH_UNROLLED(X)
+#undef X
+    return LD_ERR_SPEC;
+}
+
 bool has_unrolled(const ld_mlp_spec& spec)
 {
     if (g_force_generic.load(std::memory_order_relaxed)) return false;
@@ -290,6 +304,48 @@ int64_t auto_tile_drones(const ld_mlp_spec* spec, int64_t n, int32_t steps_per_l
     return tile < n ? tile : n;
 }
 
+// ---- part of a tile kept in the L2s ---------------------------------------------------------------------------------
+// A tile's genes are re-streamed from the Infinity Cache every timestep, and the fabric between it and the L2s is what
+// bounds the tile (8 TB/s).  The L2s themselves (8 x 4 MB) could hold a quarter of a 32-32 tile, but the non-temporal
+// stream of all of it leaves nothing in them.  So the first `cached` drones of a tile are flown by a SECOND launch, on
+// a side stream, whose gene loads are cacheable (two workgroups of 8 wavefronts per block), concurrently with the
+// rest of the tile on the caller's stream (one workgroup of 8, non-temporal): the L2s keep a good part of the first
+// group's genes from timestep to timestep and that share of the re-streams never reaches the fabric.  16 384 drones
+// of 32-32, 64 timesteps: 813 -> 745 us (scripts/exp_l2_partition.py, profiles/r02_l2_partition.json; both parts
+// non-temporal: 845-865 us, everything cacheable: 1 020 us).  Both launches run the same per-lane instruction
+// streams as any other geometry: bit-identical results.
+#ifndef LD_L2_KEEP_BYTES
+#define LD_L2_KEEP_BYTES (28u << 20)               // of the 32 MB of L2: 4 096 drones of 32-32
+#endif
+int64_t auto_cached_drones(const ld_mlp_spec* spec, int64_t tile, int32_t steps_per_launch)
+{
+    if (steps_per_launch < 4 || tile < (1 << 14) || ld_mlp_words_per_drone(spec) > 512 || !even_split(spec, 8)) return 0;
+    if (find_specialisation(*spec)) return 0;        // run-time specialisations do not carry the cacheable variant
+    const int64_t keep = ((int64_t)LD_L2_KEEP_BYTES / (4 * ld_mlp_param_count(spec))) / 64 * 64;
+    return keep * 3 <= tile ? keep : 0;              // only where it is a minor part of the tile
+}
+
+struct SideStream {                                   // one per host thread and device, made at first use
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool ready()
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (stream && dev == device) return true;
+        if (stream) { (void)hipEventDestroy(fork); (void)hipEventDestroy(join); (void)hipStreamDestroy(stream); stream = nullptr; }
+        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { stream = nullptr; return false; }
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipStreamDestroy(stream); stream = nullptr; return false;
+        }
+        device = dev;
+        return true;
+    }
+};
+thread_local SideStream t_side;
+
 int rollout_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec, const double* coins,
                       const double* walls, const float* genomes, float* fstate, int32_t* istate,
                       ld_fitness_record* records, int64_t n, int32_t timesteps, int32_t steps_per_launch, int32_t waves,
@@ -310,14 +366,33 @@ int rollout_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, con
         }
         return finalize_impl<float>(ep, coins, fstate, istate, records, nullptr, n, stream);
     }
+    const bool own_geometry = waves == 0 && tile_drones == 0;             // the library's choice: it may keep part of a tile in L2
     if (tile_drones == 0) tile_drones = auto_tile_drones(spec, n, steps_per_launch);
+    hipStream_t main = static_cast<hipStream_t>(stream);
     for (int64_t begin = 0; begin < n; begin += tile_drones) {              // a tile's whole episode, then the next tile
         const int64_t end = begin + tile_drones < n ? begin + tile_drones : n;
+        int64_t cached = own_geometry ? auto_cached_drones(spec, end - begin, steps_per_launch) : 0;
+        if (cached && !t_side.ready()) cached = 0;
+        if (cached) {                                                      // fork: the side stream joins the caller's stream here
+            hipError_t e = hipEventRecord(t_side.fork, main);
+            if (e == hipSuccess) e = hipStreamWaitEvent(t_side.stream, t_side.fork, 0);
+            if (e != hipSuccess) return hip_fail(e, "fork of the side stream");
+        }
         for (int32_t t = 0; t < timesteps; t += steps_per_launch) {
             const int32_t k = timesteps - t < steps_per_launch ? timesteps - t : steps_per_launch;
-            rc = dispatch_split_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, begin, end, k, waves,
-                                    static_cast<hipStream_t>(stream));
+            if (cached) {
+                rc = dispatch_split_cached_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, begin, begin + cached, k,
+                                               t_side.stream);
+                if (rc) return rc;
+            }
+            rc = dispatch_split_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, begin + cached, end, k,
+                                    cached ? 8 : waves, main);
             if (rc) return rc;
+        }
+        if (cached) {                                                      // join: the caller's stream waits for the side stream
+            hipError_t e = hipEventRecord(t_side.join, t_side.stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(main, t_side.join, 0);
+            if (e != hipSuccess) return hip_fail(e, "join of the side stream");
         }
     }
     return finalize_impl<float>(ep, coins, fstate, istate, records, nullptr, n, stream);
@@ -632,9 +707,17 @@ int ld_fly_rollout_geometry_f32(const ld_mlp_spec* spec, int64_t n, int32_t time
     *steps_per_launch = auto_steps_per_launch();
     *tile_drones = split && n > 0 ? auto_tile_drones(spec, n, *steps_per_launch) : n;
     *waves_per_block = split ? auto_waves_per_block(spec, *tile_drones, *steps_per_launch) : 1;
+    if (split && auto_cached_drones(spec, *tile_drones, *steps_per_launch) > 0) *waves_per_block = 8;   // the streaming part's
     const int64_t tiles = *tile_drones > 0 ? (n + *tile_drones - 1) / *tile_drones : 1;
     *n_launches = (int32_t)(tiles * ((timesteps + *steps_per_launch - 1) / *steps_per_launch));
     return LD_OK;
+}
+
+int64_t ld_fly_rollout_cached_drones_f32(const ld_mlp_spec* spec, int64_t n, int32_t timesteps)
+{
+    if (check_spec(spec) != LD_OK || n <= 0 || timesteps < 0 || !has_unrolled(*spec)) return 0;
+    const int32_t k = auto_steps_per_launch();
+    return auto_cached_drones(spec, auto_tile_drones(spec, n, k), k);
 }
 
 int ld_fly_steps_auto_waves_f32(const ld_mlp_spec* spec, int64_t n, int32_t n_steps)

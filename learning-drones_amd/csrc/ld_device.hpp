@@ -319,19 +319,19 @@ __host__ __device__ inline int64_t word_index(int64_t i, int64_t w, int64_t W)
 #define LD_GENE_NT 1
 #endif
 // lane_offset = word_index(i, 0, W)
-template <typename Real>
+template <typename Real, bool NonTemporal = (LD_GENE_NT != 0)>
 __device__ __forceinline__ GeneWord<Real> load_word(const GeneWord<Real>* __restrict__ genomes, int64_t lane_offset, int w)
 {
     const GeneWord<Real>* p = genomes + lane_offset + (int64_t)w * kGenomeBlock;
-#if LD_GENE_NT
-    using V = __attribute__((ext_vector_type(4))) Real;
-    const V v = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
-    GeneWord<Real> r;
-    r.g[0] = v.x; r.g[1] = v.y; r.g[2] = v.z; r.g[3] = v.w;
-    return r;
-#else
-    return *p;
-#endif
+    if constexpr (NonTemporal) {
+        using V = __attribute__((ext_vector_type(4))) Real;
+        const V v = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+        GeneWord<Real> r;
+        r.g[0] = v.x; r.g[1] = v.y; r.g[2] = v.z; r.g[3] = v.w;
+        return r;
+    } else {
+        return *p;
+    }
 }
 
 }  // namespace ld

@@ -125,7 +125,9 @@ __device__ __forceinline__ void split_barrier()
 // the first 64 / S lanes of its wavefronts (the other lanes leave at once).  A shard of 8 192 drones is 128
 // genome blocks: one workgroup per block occupies 128 of the 256 CUs, and each of those pulls its block's genes
 // at the most one CU can draw from L2 / Infinity Cache (~50 GB/s); two workgroups per block use every CU.
-template <typename Real, bool Faithful, int L, int S, int... H>
+// Streamed = the genes are loaded with the non-temporal hint (the default); false = cacheable loads, for the part of a
+// tile that ld_fly_rollout_f32 asks the L2s to keep (ld_abi.hip, rollout_steps_f32).
+template <typename Real, bool Faithful, int L, int S, bool Streamed, int... H>
 __global__ void __launch_bounds__(64 * L)
 fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restrict__ coins,
                  const double* __restrict__ walls, const GeneWord<Real>* __restrict__ genomes,
@@ -181,7 +183,7 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
             constexpr int N = Plan::stream_len(K);
             static_for<A, (B < N ? B : N)>([&](auto sc) __attribute__((always_inline)) {
                 constexpr int s = decltype(sc)::value;
-                ring[s] = load_word<Real>(genomes, lane_offset, Plan::word_at(K, s));
+                ring[s] = load_word<Real, Streamed>(genomes, lane_offset, Plan::word_at(K, s));
             });
         });
     };
@@ -276,7 +278,7 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
                         });
                         if constexpr (s + D < N) {
                             asm volatile("" : "+v"(lane_offset) : "v"(acc));
-                            ring[s % D] = load_word<Real>(genomes, lane_offset, Plan::word_at(K, s + D));
+                            ring[s % D] = load_word<Real, Streamed>(genomes, lane_offset, Plan::word_at(K, s + D));
                         }
                     });
                     if constexpr (L == 1) {
@@ -311,12 +313,12 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
     }
 }
 
-template <typename Real, bool Faithful, int L, int S, int... H>
+template <typename Real, bool Faithful, int L, int S, bool Streamed, int... H>
 int launch_fly_split(const ld_sim_params* sim, const ld_episode_params* ep, const double* coins, const double* walls,
                      const Real* genomes, Real* fstate, int32_t* istate, int64_t n, int64_t begin, int64_t end,
                      int32_t n_steps, hipStream_t stream)
 {
-    hipLaunchKernelGGL((fly_split_kernel<Real, Faithful, L, S, H...>), dim3(blocks_for(end - begin, 64) * S), dim3(64 * L), 0, stream,
+    hipLaunchKernelGGL((fly_split_kernel<Real, Faithful, L, S, Streamed, H...>), dim3(blocks_for(end - begin, 64) * S), dim3(64 * L), 0, stream,
                        make_sim<Real>(*sim), make_ep<Real>(*ep), coins, walls,
                        reinterpret_cast<const GeneWord<Real>*>(genomes), fstate, istate, n, begin, end, n_steps);
     return check_launch("fly_split_kernel");
@@ -327,5 +329,7 @@ int launch_fly_split(const ld_sim_params* sim, const ld_episode_params* ep, cons
 // One function per unrolled spec (ld_split_<tag>.hip): dispatch on the wavefronts per block.
 #define LD_DECLARE_SPLIT(TAG, ...)                                                                                \
     int ld_u_split_f32_##TAG(const ld_sim_params*, const ld_episode_params*, const double*, const double*,        \
-                             const float*, float*, int32_t*, int64_t, int64_t, int64_t, int32_t, int32_t, hipStream_t);
+                             const float*, float*, int32_t*, int64_t, int64_t, int64_t, int32_t, int32_t, hipStream_t); \
+    int ld_u_split_cached_f32_##TAG(const ld_sim_params*, const ld_episode_params*, const double*, const double*,  \
+                                    const float*, float*, int32_t*, int64_t, int64_t, int64_t, int32_t, hipStream_t);
 LD_FOR_EACH_UNROLLED(LD_DECLARE_SPLIT)

@@ -337,7 +337,9 @@ class Population:
                       "ld_fly_rollout_geometry_f32")
         if self.precision == "f64":             # the same timesteps per launch, one wavefront per block, no tiles
             return {"steps_per_launch": k.value, "waves_per_block": 1, "launches": -(-int(timesteps) // k.value), "tile_drones": self.n}
-        return {"steps_per_launch": k.value, "waves_per_block": w.value, "launches": m.value, "tile_drones": tile.value}
+        cached = int(_native.lib().ld_fly_rollout_cached_drones_f32(C.byref(self.spec), self.n, int(timesteps)))
+        return {"steps_per_launch": k.value, "waves_per_block": w.value, "launches": m.value, "tile_drones": tile.value,
+                "cached_drones": cached}
 
     def auto_waves_per_block(self, drones: int, steps_per_launch: int) -> int:
         """Wavefronts per genome block the library chooses (waves_per_block = 0) for a launch of `drones` drones

@@ -6,6 +6,7 @@ cd "$(dirname "$0")/.."
 P=gpurun_out/prof
 declare -A ARGS=(
   [c3]=""
+  [c3_plain]=" --tile-drones 16384"
   [c3_whole]=" --tile-drones 65536"
   [c3_k1]=" --steps-per-launch 1 --waves-per-block 1 --tile-drones 65536"
   [shard8]=" --drones 8192"
@@ -15,7 +16,7 @@ declare -A ARGS=(
   [gen12]=" --hidden 12,12 --no-specialise"
   [jit12]=" --hidden 12,12 --specialise"
 )
-for tag in c3 c3_whole c3_k1 shard8 c4 c2 c5 gen12 jit12; do
+for tag in c3 c3_plain c3_whole c3_k1 shard8 c4 c2 c5 gen12 jit12; do
   kernel=fly_split_kernel; [ $tag = gen12 ] && kernel=fly_step_kernel
   python3 scripts/profile_summary.py --out profiles/r02_${tag}_pmc.json --round 2 --kernel $kernel \
     --trace $P/${tag}_trace --fetch $P/${tag}_fetch --write $P/${tag}_write --bench $P/${tag}_trace.json \

@@ -243,8 +243,9 @@ def _replicated(hidden, m, n, seed):
 
 def test_full_size_config4_shard(Population, torch):
     """One GPU's share of BASELINE config 4: 32 768 drones x 4 000 steps, 15-32-32-4, 3-coin chain (the
-    launch geometry this shard gets: two tiles of 16 384 drones, 4 wavefronts per block, 64 timesteps per
-    launch).  Size-independent
+    launch geometry this shard gets: two tiles of 16 384 drones, 64 timesteps per launch, the first 4 288 drones (28 MB of genes) of
+    each tile flown with cacheable gene loads on the library's side stream, the rest streaming with 8 wavefronts
+    per block).  Size-independent
     properties: genomes replicated from a 256-drone population under a random permutation give the
     permuted small-population results bit for bit; a re-run is bit-identical; one launch per timestep
     and the resident engine give the same records."""
@@ -258,7 +259,7 @@ def test_full_size_config4_shard(Population, torch):
     pop = Population(n, hidden, coins=coins)
     pop.set_genomes(torch.as_tensor(genes_m, dtype=torch.float32, device="cuda")[torch.as_tensor(src, device="cuda")])
     geo = pop.rollout_geometry(T)
-    assert geo == {"steps_per_launch": 64, "waves_per_block": 4, "launches": 126, "tile_drones": 16384}
+    assert geo == {"steps_per_launch": 64, "waves_per_block": 8, "launches": 126, "tile_drones": 16384, "cached_drones": 4288}
     pop.fly(T)
     got = pop.results()
     for f in ("reward", "flight_time", "coins", "crashed", "distance_to_coin"):

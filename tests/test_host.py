@@ -182,9 +182,9 @@ def test_argument_validation_without_gpu(lib):
     geo = lambda h, n, T: (lib.ld_fly_rollout_geometry_f32(C.byref(MlpSpec.from_hidden(h)), n, T, C.byref(k), C.byref(w), C.byref(m),
                                                             C.byref(tile)), k.value, w.value, m.value, tile.value)
     # config 3: 446 MB of genes > Infinity Cache -> four tiles of 16 384 drones (111 MB each), 4 wavefronts per block
-    assert geo((32, 32), 65536, 2000) == (OK, 64, 4, 128, 16384) and geo((32, 32), 8192, 2000) == (OK, 64, 16, 32, 8192)
-    assert geo((32, 32), 32768, 4000) == (OK, 64, 4, 126, 16384)           # config 4 shard: 223 MB -> two tiles
-    assert geo((32, 32), 16384, 2000) == (OK, 64, 4, 32, 16384)
+    assert geo((32, 32), 65536, 2000) == (OK, 64, 8, 128, 16384) and geo((32, 32), 8192, 2000) == (OK, 64, 16, 32, 8192)   # 8: the streaming part of a tile whose head is kept in L2
+    assert geo((32, 32), 32768, 4000) == (OK, 64, 8, 126, 16384)           # config 4 shard: 223 MB -> two tiles
+    assert geo((32, 32), 16384, 2000) == (OK, 64, 8, 32, 16384)
     assert geo((64, 64, 64), 131072, 4000) == (OK, 64, 8, 63, 131072)     # 38 KB of genes per drone: a tile could not fill the chip; two workgroups of 4
     assert geo((64, 64, 64), 8192, 100) == (OK, 64, 8, 2, 8192) and geo((12,), 1000, 50) == (OK, 64, 1, 1, 1000)   # run-time spec: one wavefront per block, 64 timesteps per launch
     assert geo((10, 10), 65536, 2000) == (OK, 64, 2, 32, 65536)           # 82 MB: fits as it is; 10 rows split evenly over 2 wavefronts only
@@ -248,4 +248,5 @@ def test_no_fused_step_kernel_runs_out_of_scratch():
     repo = Path(__file__).resolve().parent.parent
     out = subprocess.run([sys.executable, str(repo / "scripts" / "audit_scratch.py")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
-    assert "fly_split_kernel<float, false, 4, 1, 32, 32>" in out.stdout and "fly_resident_kernel" in out.stdout
+    assert "fly_split_kernel<float, false, 4, 1, true, 32, 32>" in out.stdout and "fly_split_kernel<float, false, 8, 2, false, 32, 32>" in out.stdout
+    assert "fly_resident_kernel" in out.stdout

@@ -322,7 +322,7 @@ int64_t auto_cached_drones(const ld_mlp_spec* spec, int64_t tile, int32_t steps_
     if (steps_per_launch < 4 || tile < (1 << 14) || ld_mlp_words_per_drone(spec) > 512 || !even_split(spec, 8)) return 0;
     if (find_specialisation(*spec)) return 0;        // run-time specialisations do not carry the cacheable variant
     const int64_t keep = ((int64_t)LD_L2_KEEP_BYTES / (4 * ld_mlp_param_count(spec))) / 64 * 64;
-    return keep * 3 <= tile ? keep : 0;              // only where it is a minor part of the tile
+    return keep * 3 <= tile ? keep : 0;              // a minor part of the tile only (measured: 32-32 +7 %; with half the tile cached 16-16 -29 %, 15-16-4 -42 %, 15-64-4 +5 %)
 }
 
 struct SideStream {                                   // one per host thread and device, made at first use

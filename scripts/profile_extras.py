@@ -26,7 +26,7 @@ json.dump({"round": 2, "what": "effective shader clock of the headline kernel wh
            "effective_clock_ghz": {"mean": statistics.fmean(clocks), "min": min(clocks), "max": max(clocks)},
            "launch_us_in_this_pass": statistics.fmean(durs) / 1e3, "launch_us_kernel_trace_pass": tr["launch_us_profiled"],
            "launch_us_unprofiled_same_box": un["roofline"]["launch_us"],
-           "note": "profiled and un-profiled launch durations of one box agree within its run-to-run noise (a few per cent); round 1's 6 % gap "
+           "note": "rocprofv3 serialises kernels while it collects counters, so the two concurrent kernels of a launch (cached head on the side stream + streaming rest) appear here one after the other: launch_us_in_this_pass is their per-kernel average, not the launch; profiled and un-profiled launch durations of one box agree within its run-to-run noise (a few per cent); round 1's 6 % gap "
                    "(71.8 vs 67.5 us) was measured on two different boxes of the pool: this round's un-profiled runs of one binary "
                    "spread over 62.3-64.7 us per timestep (whole-population launches) across boxes"},
           open("profiles/r02_c3_clock.json", "w"), indent=1)

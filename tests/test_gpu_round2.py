@@ -616,3 +616,35 @@ def test_bench_two_ranks_on_one_gpu_rehearses_the_multi_gpu_flow():
     assert s["scaling"] == "strong" and s["population"] == 8192 and s["drones_per_gpu"] == 4096 and s["records"]["rows"] == 8192
     assert d["generation"]["error"] is None and d["generations_per_s"] > 0
     assert "cpu_baseline" not in d                                        # rank 0 at N = 1 only
+
+
+def test_cached_tile_head_on_the_side_stream_is_bit_identical(Population, torch):
+    """The default rollout of a population of >= 16 384 drones of 32-32 flies the head of each tile (28 MB of genes) with
+    cacheable gene loads in a second launch on a side stream of the library's, concurrently with the streaming rest: a
+    ragged population (one full tile + a short one), walls, coins collected, crashes -- state, bookkeeping and
+    records equal the same tiles flown plainly (one kernel per launch), run after run, also from a non-default
+    stream of the caller's, and work enqueued behind fly() sees the finished episode."""
+    hidden, m, T = (32, 32), 256, 330
+    n = 2 * 16384 + 16384 + 192                                           # three tiles; the last one is too short for a cached head
+    genes_m, src = _replicated(hidden, m, n, seed=11)
+    walls = np.array([[3.0, 3.0, 8.0, 4.5, 7.0, 12.0]])
+    pop = Population(n, hidden, walls=walls, coins=coin_chain_reference(2))
+    pop.set_genomes(torch.as_tensor(genes_m, dtype=torch.float32, device="cuda")[torch.as_tensor(src, device="cuda")])
+    geo = pop.rollout_geometry(T)
+    assert geo["tile_drones"] == 16384 and geo["cached_drones"] == 4288 and geo["waves_per_block"] == 8
+    pop.fly(T, tile_drones=16384)                                         # explicit geometry: one kernel per launch
+    want = (pop.fstate.clone(), pop.istate.clone(), pop.records.clone())
+    crashed = (want[1][2] & 1).bool()
+    assert crashed.any() and not crashed.all() and int(want[1][1].max()) >= 1
+    for rep in range(3):
+        pop.reset()
+        pop.fly(T)
+        summed = pop.records.sum(dim=0)                                   # enqueued behind fly() on the same stream
+        assert torch.equal(pop.fstate, want[0]) and torch.equal(pop.istate, want[1]) and torch.equal(pop.records, want[2]), rep
+        assert torch.equal(summed, want[2].sum(dim=0))
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                                         # the caller's own stream
+        pop.reset()
+        pop.fly(T)
+    side.synchronize()
+    assert torch.equal(pop.fstate, want[0]) and torch.equal(pop.records, want[2])

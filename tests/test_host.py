@@ -250,3 +250,16 @@ def test_no_fused_step_kernel_runs_out_of_scratch():
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "fly_split_kernel<float, false, 4, 1, true, 32, 32>" in out.stdout and "fly_split_kernel<float, false, 8, 2, false, 32, 32>" in out.stdout
     assert "fly_resident_kernel" in out.stdout
+
+
+def test_build_flags_per_translation_unit():
+    """The multi-wavefront step kernels of layer specs with a hidden layer narrower than 16 are built without SimplifyCFG's
+    common-code sinking (build.py, NO_SINK); every other translation unit with the plain flags."""
+    from pathlib import Path
+    from learning_drones_amd import build as B
+    no_sink = "-simplifycfg-sink-common=false"
+    for name, want in (("ld_split_10_10.hip", True), ("ld_split_8_8.hip", True), ("ld_split_8_10.hip", True), ("ld_split_16.hip", False),
+                       ("ld_split_32_32.hip", False), ("ld_split_64_64_64_W8.hip", False), ("ld_resident.hip", False), ("ld_abi.hip", False)):
+        assert (no_sink in B.flags_for(Path(name))) is want, name
+    assert B.narrow((12, 12)) and B.narrow((13, 7)) and not B.narrow((20, 20)) and not B.narrow((16,))
+    assert "-ffp-contract=off" in B.FLAGS and "-fno-slp-vectorize" in B.FLAGS

@@ -267,8 +267,8 @@ int ld_fly_finalize_f64(const ld_episode_params *ep, const double *coins, const 
  * (identical results).  _f64 and the float32 specs without an unrolled specialisation: one wavefront per genome
  * block.  The unrolled float32 specs take ld_fly_rollout_steps_f32's default geometry, and for tiles of
  * >= 16 384 drones the head of each tile is flown concurrently on a side stream the library owns (one per host
- * thread and device, created at first use, forked from and joined to `stream` by events): see
- * ld_fly_rollout_cached_drones_f32. */
+ * thread and device, created at first use, forked from and joined to `stream` by events, which also works under
+ * stream capture: a whole episode can be captured into a HIP graph and replayed): see ld_fly_rollout_cached_drones_f32. */
 int ld_fly_rollout_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
                        const double *coins, const double *walls, const float *genomes,
                        float *fstate, int32_t *istate, ld_fitness_record *records,

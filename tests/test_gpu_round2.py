@@ -648,3 +648,27 @@ def test_cached_tile_head_on_the_side_stream_is_bit_identical(Population, torch)
         pop.fly(T)
     side.synchronize()
     assert torch.equal(pop.fstate, want[0]) and torch.equal(pop.records, want[2])
+
+
+def test_rollout_is_capturable_in_a_hip_graph(Population, torch):
+    """ld_fly_rollout_f32 enqueues everything from C on the caller's stream (and forks / joins its side stream by
+    events), so a whole episode can be captured into a HIP graph and replayed: same records."""
+    from bench import make_genomes
+    n, T = 16384, 200
+    pop = Population(n, (32, 32), coins=coin_chain_reference(3))
+    pop.set_genomes(make_genomes(torch, n, (32, 32), pop.device, 0))
+    assert pop.rollout_geometry(T)["cached_drones"] > 0                   # the captured episode includes the side stream
+    pop.fly(T)
+    want = pop.records.clone()
+    pop.reset()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        pop.fly(T)
+    for _ in range(2):
+        pop.records.zero_()
+        pop.reset()
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(pop.records, want)

@@ -154,6 +154,10 @@ int ld_version(void);
 /* Test hook (process-wide, not part of the data path): non-zero routes every controller spec to the
  * generic run-time-spec kernels even where an unrolled specialisation exists.  Returns the old value. */
 int ld_debug_force_generic(int on);
+/* Process-wide switch for the genes a launch of several timesteps keeps in LDS (fly_split_kernel<..., KeepKiB>):
+ * -1 = the library's choice (the default: launches of 8 timesteps or more), 0 = never, 1 = always.  Results do not
+ * depend on it.  Returns the old value. */
+int ld_debug_lds_keep(int mode);
 const char *ld_strerror(int status);
 /* Text of the last HIP error seen by the calling thread ("" if none). */
 const char *ld_last_hip_error(void);

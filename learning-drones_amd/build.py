@@ -43,7 +43,21 @@ def narrow(hidden) -> bool:
     return min(int(h) for h in hidden) < 16
 
 
+def keeps_in_lds(hidden) -> bool:
+    """Layer specs of up to 512 gene words: their 8-wavefront step kernels exist in a variant that keeps part of the
+    genes in LDS for the whole launch (csrc/ld_split.hpp, KeepPlan), in a translation unit of its own
+    (ld_split_keep_<tag>.hip) that is always built with NO_SINK: the fill and read-back statements look alike in every
+    wavefront's arm of the switch as well (32-32 without it: the gene ring in 272 bytes of scratch per lane)."""
+    n_in, genes = 15, 0
+    for h in tuple(int(h) for h in hidden) + (4,):
+        genes += h * (n_in + 1)
+        n_in = h
+    return (genes + 3) // 4 <= 512
+
+
 def flags_for(src: Path):
+    if src.name.startswith("ld_split_keep_"):
+        return FLAGS + NO_SINK
     if src.name.startswith("ld_split_"):
         widths = [t for t in src.stem[len("ld_split_"):].split("_") if t.isdigit()]
         return FLAGS + (NO_SINK if narrow(widths) else [])
@@ -138,8 +152,10 @@ def build_specialisation(hidden, verbose: bool = False) -> Path:
     lanes = resident_lanes(hidden)
     JIT_DIR.mkdir(parents=True, exist_ok=True)
     src, lib = JIT_DIR / f"ld_spec_{tag}.hip", JIT_DIR / f"libld_spec_{tag}.so"
+    keep = keeps_in_lds(hidden)
     text = (f"// generated by learning_drones_amd.build.build_specialisation({hidden})\n"
             f"#define LD_TAG jit_{tag}\n#define LD_WIDTHS {widths}\n#define LD_ONLY_F32\n#define LD_NO_CACHED_SPLIT\n"
+            + ("#define LD_SPLIT_HAS_KEEP\n" if keep else "") +
             f'#include "{CSRC}/ld_unrolled.inc"\n#include "{CSRC}/ld_split.inc"\n#include "{CSRC}/ld_resident.hpp"\n'
             'extern "C" int ld_spec_fly_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, const double* coins, '
             "const double* walls, const float* genomes, float* fstate, int32_t* istate, int64_t n, int64_t begin, int64_t end, "
@@ -148,30 +164,55 @@ def build_specialisation(hidden, verbose: bool = False) -> Path:
             "waves_per_block, static_cast<hipStream_t>(stream)); }\n"
             'extern "C" int ld_spec_mlp_forward_f32(const ld_mlp_spec* spec, const float* genomes, const float* inputs, '
             "float* outputs, int64_t n, void* stream)\n"
-            f"{{ return ld_u_mlp_f32_jit_{tag}(spec, genomes, inputs, outputs, n, static_cast<hipStream_t>(stream)); }}\n")
+            f"{{ return ld_u_mlp_f32_jit_{tag}(spec, genomes, inputs, outputs, n, static_cast<hipStream_t>(stream)); }}\n"
+            # the text of the last HIP error seen by THIS object's launches (its own copy of ld::g_hip_error: the object
+            # is loaded RTLD_LOCAL), for _native.check()
+            'extern "C" const char* ld_spec_last_hip_error(void) { return ld::g_hip_error; }\n')
     if lanes:
         text += ('extern "C" int ld_spec_fly_resident_f32(const ld_sim_params* sim, const ld_episode_params* ep, const double* coins, '
                  "const double* walls, const float* genomes, float* fstate, int32_t* istate, int64_t n, int32_t n_steps, "
                  "int32_t* queue, void* stream)\n"
                  f"{{ return ld::launch_fly_resident<float, false, {lanes}, {widths}>(sim, ep, coins, walls, genomes, fstate, istate, n, "
                  "n_steps, queue, static_cast<hipStream_t>(stream)); }\n")
+    keep_text = (f"// generated by learning_drones_amd.build.build_specialisation({hidden}): the LDS-keeping step kernels\n"
+                 f"#define LD_TAG jit_{tag}\n#define LD_WIDTHS {widths}\n#define LD_SPLIT_KEEP_TU\n"
+                 f'#include "{CSRC}/ld_split.inc"\n') if keep else ""
+    text += "// ---- second translation unit\n" + keep_text if keep else ""
     newest = max(p.stat().st_mtime for p in HEADERS + [Path(__file__)])
     if lib.exists() and src.exists() and src.read_text() == text and lib.stat().st_mtime >= newest:
         return lib
     # several ranks of one job may get here at once: each compiles its own copy and renames it into place
-    # (os.replace is atomic; the copies are identical)
-    mine = JIT_DIR / f"ld_spec_{tag}.{os.getpid()}.hip"
-    mine.write_text(text)
-    tmp = JIT_DIR / f"libld_spec_{tag}.{os.getpid()}.so"
-    cmd = [hipcc(), *FLAGS, *(NO_SINK if narrow(hidden) else []), "-shared", str(mine), "-o", str(tmp)]
-    if verbose:
-        print("[learning-drones_amd] " + " ".join(cmd), flush=True)
+    # (os.replace is atomic; the copies are identical; the source goes first, so that nobody sees a new library
+    # beside an old source and compiles again)
+    pid = os.getpid()
+    main_text = text.split("// ---- second translation unit\n")[0]
+    units = [(JIT_DIR / f"ld_spec_{tag}.{pid}.a.hip", main_text, FLAGS + (NO_SINK if narrow(hidden) else []))]
+    if keep:
+        units.append((JIT_DIR / f"ld_spec_{tag}.{pid}.b.hip", keep_text, FLAGS + NO_SINK))
+    mine = JIT_DIR / f"ld_spec_{tag}.{pid}.hip"
+    tmp = JIT_DIR / f"libld_spec_{tag}.{pid}.so"
+    objs = [u[0].with_suffix(".o") for u in units]
     try:
+        for path, unit_text, _ in units:
+            path.write_text(unit_text)
+
+        def compile_unit(unit):
+            cmd = [hipcc(), *unit[2], "-c", str(unit[0]), "-o", str(unit[0].with_suffix(".o"))]
+            if verbose:
+                print("[learning-drones_amd] " + " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+
+        with ThreadPoolExecutor(len(units)) as pool:
+            list(pool.map(compile_unit, units))
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(tmp), *map(str, objs)]
+        if verbose:
+            print("[learning-drones_amd] " + " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        os.replace(tmp, lib)
+        mine.write_text(text)
         os.replace(mine, src)
+        os.replace(tmp, lib)
     finally:
-        for leftover in (tmp, mine):
+        for leftover in [tmp, mine] + objs + [u[0] for u in units]:
             if leftover.exists():
                 leftover.unlink()
     return lib

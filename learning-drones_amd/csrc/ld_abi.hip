@@ -34,7 +34,19 @@ using ld::launch_mlp;
 
 namespace {
 
-std::atomic<int> g_force_generic{0};          // ld_debug_force_generic: the library's only process-wide state
+std::atomic<int> g_force_generic{0};          // ld_debug_force_generic
+std::atomic<int> g_lds_keep{-1};              // ld_debug_lds_keep: -1 = the library's choice, 0 = never, 1 = always
+
+// Launches of this many timesteps or more keep part of every block's genes in LDS (fly_split_kernel<..., KeepKiB>):
+// the one-off fill costs about one timestep's worth of that share.
+#ifndef LD_KEEP_MIN_STEPS
+#define LD_KEEP_MIN_STEPS 8
+#endif
+int keep_bit(int32_t n_steps)
+{
+    const int mode = g_lds_keep.load(std::memory_order_relaxed);
+    return mode == 0 ? 0 : (mode > 0 || n_steps >= LD_KEEP_MIN_STEPS) ? 0x100 : 0;
+}
 
 // Specs specialised at run time (ld_register_specialisation_f32): the library's other process-wide state.
 struct Specialisation {
@@ -147,9 +159,26 @@ bool even_split(const ld_mlp_spec* spec, int waves_per_workgroup)
     return true;
 }
 
+// Launches that keep genes in LDS (fly_split_kernel<..., KeepKiB>; n_steps >= LD_KEEP_MIN_STEPS, nets of up to 512 gene
+// words with an even split over 8 wavefronts): a workgroup of 8 wavefronts fills its CU's LDS with 136 KiB of its drones'
+// genes, so what matters is that every CU has exactly one workgroup: the fewest workgroups per block that give the
+// launch 256 of them.  32-32, 64 timesteps per launch, us per launch at 8 / 16 / 32 wavefronts per block
+// (scripts/exp_lds_keep.py, profiles/r03_lds_keep.json): 16 384 drones 598 / 700 / 841 (without keeping: 817 / 885 / 1 503),
+// 8 192: 425 / 351 / 423 (567 / 433 / 751), 4 096: 373 / 349 / 212 (492 / 385 / 374), 65 536 in one launch: 2 592 / 2 778 / 3 340
+// (3 760 / 3 668 / 6 034).
+bool keeps_genes(const ld_mlp_spec* spec, int32_t n_steps)
+{
+    return keep_bit(n_steps) != 0 && ld_mlp_words_per_drone(spec) <= 512 && even_split(spec, 8);
+}
+
 int auto_waves_per_block(const ld_mlp_spec* spec, int64_t n, int32_t n_steps)
 {
     const int64_t blocks = (n + 63) / 64;
+    if (keeps_genes(spec, n_steps)) {
+        int groups = 1;
+        while (groups < 4 && blocks * groups < 256) groups *= 2;
+        return 8 * groups;
+    }
     const int64_t target = n_steps > 1 ? 2048 : 1024;
     const int64_t words = ld_mlp_words_per_drone(spec);
     const bool wide = words > 512;
@@ -189,6 +218,7 @@ int dispatch_split_f32(const ld_sim_params* sim, const ld_episode_params* ep, co
                        int64_t end, int32_t n_steps, int32_t waves, hipStream_t stream)
 {
     if (waves == 0) waves = auto_waves_per_block(spec, end - begin, n_steps);
+    waves |= keep_bit(n_steps);                  // (only the 8-wavefront workgroups of the nets of up to 512 words act on it)
 #define X(TAG, ...)                                                                                          \
     if (spec_is<__VA_ARGS__>(*spec))                                                                         \
         return ld_u_split_f32_##TAG(sim, ep, coins, walls, genomes, fstate, istate, n, begin, end, n_steps, waves, stream);
@@ -207,7 +237,8 @@ int dispatch_split_cached_f32(const ld_sim_params* sim, const ld_episode_params*
 {
 #define X(TAG, ...)                                                                                          \
     if (spec_is<__VA_ARGS__>(*spec))                                                                         \
-        return ld_u_split_cached_f32_##TAG(sim, ep, coins, walls, genomes, fstate, istate, n, begin, end, n_steps, stream);
+        return ld_u_split_cached_f32_##TAG(sim, ep, coins, walls, genomes, fstate, istate, n, begin, end, n_steps, stream, \
+                                           keep_bit(n_steps));
     LD_FOR_EACH_UNROLLED(X)
 #undef X
     return LD_ERR_SPEC;
@@ -629,6 +660,8 @@ int ld_ga_breed_f64(const ld_ga_params* ga, const ld_mlp_spec* spec, const doubl
 int ld_version(void) { return LD_ABI_VERSION; }
 
 int ld_debug_force_generic(int on) { return g_force_generic.exchange(on ? 1 : 0); }
+
+int ld_debug_lds_keep(int mode) { return g_lds_keep.exchange(mode < 0 ? -1 : mode ? 1 : 0); }
 
 int ld_register_specialisation_f32(const ld_mlp_spec* spec, ld_fly_steps_f32_fn fly_steps, ld_mlp_forward_f32_fn mlp_forward,
                                    ld_fly_resident_f32_fn fly_resident)

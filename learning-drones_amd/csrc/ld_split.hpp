@@ -70,6 +70,59 @@ template <int L, int... H> struct SplitPlan {
     static constexpr int xch_rows = L > 1 ? xch_row(NL) : 1;
 };
 
+// Genes kept in LDS for the whole launch (KeepWords > 0).  A launch of K timesteps re-streams every gene K times;
+// the CU's 160 KiB of LDS are otherwise idle (the exchange rows and the tables take 19 KiB), so a workgroup that
+// has the CU to itself (L = 8: 227 registers per wavefront = two wavefronts per SIMD = one workgroup per CU) loads
+// KeepWords of its block's gene words into LDS once, at the top of the launch, and reads them from there on every
+// timestep: that share of the stream never reaches L2, the Infinity Cache or HBM again.  Each wavefront keeps the
+// same fraction of ITS stream, spread evenly over it (position s is kept when floor((s+1) R / N) > floor(s R / N)),
+// so the ring of streamed words advances at an even, lower rate.  A kept word is read back by the lane that wrote
+// it (ds_read_b128 of 64 consecutive 16-byte slots: conflict-free), so no barrier is involved, and every neuron's
+// sum still runs over the same genes in the same order: results are bit-identical to KeepWords = 0.
+template <int L, int KeepWords, int... H> struct KeepPlan {
+    using Plan = SplitPlan<L, H...>;
+    static constexpr int total()
+    {
+        int t = 0;
+        for (int k = 0; k < L; ++k) t += Plan::stream_len(k);
+        return t;
+    }
+    static constexpr int count(int k)                           // kept words of wavefront k
+    {
+        const int want = (int)((long long)Plan::stream_len(k) * KeepWords / total());
+        return want < Plan::stream_len(k) ? want : Plan::stream_len(k);
+    }
+    static constexpr int base(int k)                            // first LDS row of wavefront k
+    {
+        int b = 0;
+        for (int j = 0; j < k; ++j) b += count(j);
+        return b;
+    }
+    static constexpr int rows = base(L) + 2;                     // (+2: the top-of-step reads of a wavefront with fewer than two kept words)
+    static constexpr int kept_before(int k, int s) { return (int)((long long)s * count(k) / Plan::stream_len(k)); }
+    static constexpr bool kept(int k, int s) { return count(k) > 0 && kept_before(k, s + 1) != kept_before(k, s); }
+    static constexpr int streamed_before(int k, int s) { return s - kept_before(k, s); }
+    static constexpr int streamed_len(int k) { return Plan::stream_len(k) - count(k); }
+    static constexpr int max_streamed_len()
+    {
+        int m = 0;
+        for (int k = 0; k < L; ++k) m = streamed_len(k) > m ? streamed_len(k) : m;
+        return m;
+    }
+    static constexpr int pos_of_streamed(int k, int q)          // stream position of the q-th streamed word
+    {
+        for (int s = 0; s < Plan::stream_len(k); ++s)
+            if (!kept(k, s) && streamed_before(k, s) == q) return s;
+        return 0;
+    }
+    static constexpr int pos_of_kept(int k, int j)              // stream position of the j-th kept word
+    {
+        for (int s = 0; s < Plan::stream_len(k); ++s)
+            if (kept(k, s) && kept_before(k, s) == j) return s;
+        return 0;
+    }
+};
+
 // f(integral_constant<K>) for the K that equals `wave` (wave-uniform), as a switch:
 // with independent ifs the compiler must assume that a later block can run after an earlier one and
 // puts an s_waitcnt vmcnt(0) in front of it for the ring registers both write.
@@ -127,7 +180,8 @@ __device__ __forceinline__ void split_barrier()
 // at the most one CU can draw from L2 / Infinity Cache (~50 GB/s); two workgroups per block use every CU.
 // Streamed = the genes are loaded with the non-temporal hint (the default); false = cacheable loads, for the part of a
 // tile that ld_fly_rollout_f32 asks the L2s to keep (ld_abi.hip, rollout_steps_f32).
-template <typename Real, bool Faithful, int L, int S, bool Streamed, int... H>
+// KeepKiB > 0: that many KiB of the workgroup's LDS hold gene words for the whole launch (KeepPlan above).
+template <typename Real, bool Faithful, int L, int S, bool Streamed, int KeepKiB, int... H>
 __global__ void __launch_bounds__(64 * L)
 fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restrict__ coins,
                  const double* __restrict__ walls, const GeneWord<Real>* __restrict__ genomes,
@@ -146,12 +200,18 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
     constexpr int kWantBase = sizeof(Real) == 4 ? (Shape::W <= 512 ? LD_DEPTH_F32_SMALL_NET : LD_DEPTH_F32) : LD_DEPTH_F64;
     constexpr int kCap = L >= 8 ? LD_SPLIT_DEPTH_CAP_L8 : LD_SPLIT_DEPTH_CAP;
     constexpr int kWant = kWantBase < kCap ? kWantBase : kCap;
-    constexpr int D = kWant < Plan::max_stream_len() ? kWant : Plan::max_stream_len();
+    constexpr int kLanes = 64 / S;                            // drones (= active lanes) per wavefront
+    constexpr int kKeepWords = KeepKiB * 1024 / (kLanes * (int)sizeof(GeneWord<Real>));
+    using Keep = KeepPlan<L, kKeepWords, H...>;
+    constexpr bool kKeeps = kKeepWords > 0;
+    constexpr int kStreamMax = Keep::max_streamed_len() > 0 ? Keep::max_streamed_len() : 1;
+    constexpr int D = kWant < kStreamMax ? kWant : kStreamMax;
+    constexpr int KD = 2;                                     // kept words in flight from LDS per lane
 
     __shared__ Tables<Real> tab;
     __shared__ Real xch[Plan::xch_rows][64];
+    __shared__ GeneWord<Real> kept[Keep::rows][kLanes];
 
-    constexpr int kLanes = 64 / S;                            // drones (= active lanes) per wavefront
     const int lane = threadIdx.x & 63;
     if (S > 1 && lane >= kLanes) return;
     const int wave = L == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -180,13 +240,36 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
         constexpr int B = decltype(part)::value == 0 ? kHead : D;
         LD_PREFETCH_DISPATCH<L>(wave, [&](auto kc) __attribute__((always_inline)) {
             constexpr int K = decltype(kc)::value;
-            constexpr int N = Plan::stream_len(K);
-            static_for<A, (B < N ? B : N)>([&](auto sc) __attribute__((always_inline)) {
-                constexpr int s = decltype(sc)::value;
-                ring[s] = load_word<Real, Streamed>(genomes, lane_offset, Plan::word_at(K, s));
+            constexpr int N = Keep::streamed_len(K);
+            static_for<A, (B < N ? B : N)>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int q = decltype(qc)::value;
+                ring[q] = load_word<Real, Streamed>(genomes, lane_offset, Plan::word_at(K, Keep::pos_of_streamed(K, q)));
             });
         });
     };
+    // ---- the kept words: loaded once per launch, through the ring's registers, D at a time.  A block that is
+    // frozen already leaves before (its status word is the one load this waits for).
+    const GeneWord<Real>* my_kept = &kept[0][lane];
+    if constexpr (kKeeps) {
+        if (__all((status_loaded & 1) || !valid)) return;     // every wavefront of the workgroup sees the same drones
+        LD_PREFETCH_DISPATCH<L>(wave, [&](auto kc) __attribute__((always_inline)) {
+            constexpr int K = decltype(kc)::value;
+            constexpr int R = Keep::count(K);
+            my_kept = &kept[Keep::base(K)][lane];
+            static_for<0, (R + D - 1) / D>([&](auto cc) __attribute__((always_inline)) {
+                constexpr int c0 = decltype(cc)::value * D, c1 = c0 + D < R ? c0 + D : R;
+                static_for<c0, c1>([&](auto jc) __attribute__((always_inline)) {
+                    constexpr int j = decltype(jc)::value;
+                    ring[j - c0] = load_word<Real, true>(genomes, lane_offset, Plan::word_at(K, Keep::pos_of_kept(K, j)));
+                });
+                static_for<c0, c1>([&](auto jc) __attribute__((always_inline)) {
+                    constexpr int j = decltype(jc)::value;
+                    kept[Keep::base(K) + j][lane] = ring[j - c0];
+                });
+            });
+        });
+    }
+    GeneWord<Real> kring[KD];
     // One prefetch site only (at the top of the loop body): with a second one behind the last layer the
     // register allocator keeps two copies of the ring.
     bool dead0 = false, dead = false;
@@ -194,6 +277,10 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
     for (int32_t t = 0; t < n_steps; ++t) {
         if (t > 0 && __all(dead)) break;                      // every wavefront of the block sees the same 64 drones
         prefetch(std::integral_constant<int, 0>{});
+        if constexpr (kKeeps) {
+#pragma unroll
+            for (int j = 0; j < KD; ++j) kring[j] = my_kept[j * kLanes];      // (a wavefront with fewer kept words reads rows it never uses)
+        }
         // Nothing above may wait: everything below that reads a loaded value stays below this line (the
         // laundered status keeps the compiler from hoisting the frozen test in front of the prefetch,
         // where its s_waitcnt would serialise the state latency and the gene latency).
@@ -242,7 +329,6 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
         LD_FORWARD_DISPATCH<L>(wave, [&](auto kc) __attribute__((always_inline)) {
             constexpr int K = decltype(kc)::value;
             {
-                constexpr int N = Plan::stream_len(K);
                 static_for<0, NL>([&](auto lc) __attribute__((always_inline)) {
                     constexpr int layer = decltype(lc)::value;
                     constexpr int n_in = Shape::dims[layer], n_out = Shape::dims[layer + 1];
@@ -259,7 +345,9 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
                         // the software pipeline of UnrolledNet::forward (ld_nets.hpp): nothing moves across the
                         // sched_barrier, and the refill's address depends on this word's result
                         __builtin_amdgcn_sched_barrier(0);
-                        const GeneWord<Real> v = ring[s % D];
+                        constexpr bool from_lds = Keep::kept(K, s);
+                        constexpr int kj = Keep::kept_before(K, s), sq = Keep::streamed_before(K, s);
+                        const GeneWord<Real> v = from_lds ? kring[kj % KD] : ring[sq % D];
                         static_for<0, 4>([&](auto cc) __attribute__((always_inline)) {
                             constexpr int cidx = decltype(cc)::value;
                             constexpr int p = 4 * w + cidx;
@@ -276,9 +364,12 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
                                 }
                             }
                         });
-                        if constexpr (s + D < N) {
+                        if constexpr (from_lds) {
+                            if constexpr (kj + KD < Keep::count(K)) kring[kj % KD] = my_kept[(kj + KD) * kLanes];
+                        } else if constexpr (sq + D < Keep::streamed_len(K)) {
                             asm volatile("" : "+v"(lane_offset) : "v"(acc));
-                            ring[s % D] = load_word<Real, Streamed>(genomes, lane_offset, Plan::word_at(K, s + D));
+                            ring[sq % D] = load_word<Real, Streamed>(genomes, lane_offset,
+                                                                     Plan::word_at(K, Keep::pos_of_streamed(K, sq + D)));
                         }
                     });
                     if constexpr (L == 1) {
@@ -313,12 +404,12 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
     }
 }
 
-template <typename Real, bool Faithful, int L, int S, bool Streamed, int... H>
+template <typename Real, bool Faithful, int L, int S, bool Streamed, int KeepKiB, int... H>
 int launch_fly_split(const ld_sim_params* sim, const ld_episode_params* ep, const double* coins, const double* walls,
                      const Real* genomes, Real* fstate, int32_t* istate, int64_t n, int64_t begin, int64_t end,
                      int32_t n_steps, hipStream_t stream)
 {
-    hipLaunchKernelGGL((fly_split_kernel<Real, Faithful, L, S, Streamed, H...>), dim3(blocks_for(end - begin, 64) * S), dim3(64 * L), 0, stream,
+    hipLaunchKernelGGL((fly_split_kernel<Real, Faithful, L, S, Streamed, KeepKiB, H...>), dim3(blocks_for(end - begin, 64) * S), dim3(64 * L), 0, stream,
                        make_sim<Real>(*sim), make_ep<Real>(*ep), coins, walls,
                        reinterpret_cast<const GeneWord<Real>*>(genomes), fstate, istate, n, begin, end, n_steps);
     return check_launch("fly_split_kernel");
@@ -331,5 +422,5 @@ int launch_fly_split(const ld_sim_params* sim, const ld_episode_params* ep, cons
     int ld_u_split_f32_##TAG(const ld_sim_params*, const ld_episode_params*, const double*, const double*,        \
                              const float*, float*, int32_t*, int64_t, int64_t, int64_t, int32_t, int32_t, hipStream_t); \
     int ld_u_split_cached_f32_##TAG(const ld_sim_params*, const ld_episode_params*, const double*, const double*,  \
-                                    const float*, float*, int32_t*, int64_t, int64_t, int64_t, int32_t, hipStream_t);
+                                    const float*, float*, int32_t*, int64_t, int64_t, int64_t, int32_t, hipStream_t, int32_t);
 LD_FOR_EACH_UNROLLED(LD_DECLARE_SPLIT)

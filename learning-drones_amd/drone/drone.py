@@ -8,7 +8,7 @@ from __future__ import annotations
 import numpy as np
 
 from ..evolve.brain import NeuralNetwork
-from ..params import EpisodeParams, SimParams, flatten_weights
+from ..params import EpisodeParams, SimParams, controller_spec, flatten_weights
 from .onboard_computer import ControlUnit
 from .quadcopter import QuadcopterPhysics
 
@@ -83,7 +83,7 @@ class Drone(ControlUnit):
 
     def _population(self):
         from ..scalar import scalar_population
-        return scalar_population(self.controller.spec, self.precision)
+        return scalar_population(controller_spec(self.controller), self.precision)
 
     # ---- reference methods
     def enable_visualization(self, visualize, n_servers, port, dir_name="./rewatch"):

@@ -25,7 +25,8 @@ def main(argv) -> int:
     from .flight import fly
     from .population import Population
     drone = load_drone(path)
-    pop = Population(1, drone.controller.spec.hidden_widths, precision=drone.precision)
+    from .params import controller_spec
+    pop = Population(1, controller_spec(drone.controller).hidden_widths, precision=drone.precision)
     pop.set_genomes(drone.genes[None, :])
     os.makedirs(out_dir, exist_ok=True)
     pop.record_trajectory(timesteps, slots=(0,), csv_prefix=os.path.join(out_dir, "Results_"))

@@ -231,3 +231,17 @@ def spec_of_weights(weights: Sequence[np.ndarray]) -> MlpSpec:
         if d != a + 1:
             raise ValueError(f"inconsistent layer shapes {shapes}")
     return MlpSpec.from_hidden([s[0] for s in shapes[:-1]])
+
+
+def controller_spec(controller) -> MlpSpec:
+    """The layer spec of a controller object.  The reference's contract for a controller is an object with a
+    ``.weights`` list of (n_out, n_in + 1) arrays (evolve/brain.py:10-24; drone/drone.py:65,83-86): this package's
+    NeuralNetwork also carries ``.spec``, anything else (the reference's own NeuralNetwork, a hand-made stand-in) is
+    read through its weights."""
+    spec = getattr(controller, "spec", None)
+    if isinstance(spec, MlpSpec):
+        return spec
+    if not hasattr(controller, "weights"):
+        raise TypeError(f"{type(controller).__name__} has no .weights: not a network controller (evolve/brain.py:10-24)")
+    return spec_of_weights(controller.weights)
+

@@ -57,8 +57,10 @@ static void matmul3(const double A[3][3], const double B[3][3], double C[3][3])
 
 /* QuadcopterPhysics.calculate_accelerations, physical_model.py:75-122, with every float32
  * rounding point of the reference kept (marked (1)-(4)). */
-static void accel_faithful(const ld_sim_params *p, const double ang[3], const double u[4],
-                           double lin[3], double rot[3])
+/* `lab` = the reference's lin_acc_drone_2_lab argument: 0 returns the body-frame pair of :114-115 before Rot^T and
+ * Tr are applied (:117-120).  rot_out (may be NULL): self.Rot as the call leaves it (:90), row-major. */
+static void accel_faithful_frames(const ld_sim_params *p, const double ang[3], const double u[4],
+                                  double lin[3], double rot[3], double *rot_out, int lab)
 {
     const double roll = ang[0], pitch = ang[1], yaw = ang[2];
     const double cr = cos(roll), sr = sin(roll), cp = cos(pitch), sp = sin(pitch);
@@ -92,6 +94,13 @@ static void accel_faithful(const ld_sim_params *p, const double ang[3], const do
     const float m32 = (float)p->mass_total;
     const float a32[3] = {F[0] / m32, F[1] / m32, F[2] / m32};      /* (4) stays float32 */
     const double b[3] = {mom[0] * p->inv_inertia[0], mom[1] * p->inv_inertia[1], mom[2] * p->inv_inertia[2]};
+    if (rot_out)
+        for (int i = 0; i < 3; ++i)
+            for (int k = 0; k < 3; ++k) rot_out[3 * i + k] = B[k][i];
+    if (!lab) {                               /* :117 not taken: the float32 forces / m and the float64 moments / I */
+        for (int i = 0; i < 3; ++i) { lin[i] = (double)a32[i]; rot[i] = b[i]; }
+        return;
+    }
     /* :118  Rot^T . lin_acc */
     for (int i = 0; i < 3; ++i)
         lin[i] = dot3_gemv_c(B[i][0], (double)a32[0], B[i][1], (double)a32[1], B[i][2], (double)a32[2]);
@@ -102,6 +111,12 @@ static void accel_faithful(const ld_sim_params *p, const double ang[3], const do
                             {0.0f, (float)(sr / cp), (float)(cr / cp)}};
     for (int i = 0; i < 3; ++i)
         rot[i] = dot3_gemv_c((double)Tr[i][0], b[0], (double)Tr[i][1], b[1], (double)Tr[i][2], b[2]);
+}
+
+static void accel_faithful(const ld_sim_params *p, const double ang[3], const double u[4],
+                           double lin[3], double rot[3])
+{
+    accel_faithful_frames(p, ang, u, lin, rot, NULL, 1);
 }
 
 /* ---- float64 instantiation (faithful + closed) ---- */
@@ -185,6 +200,14 @@ int ldo_accelerations(const ld_sim_params *sim, const double angle[3], const dou
     } else {
         accel_f64(sim, angle, thrust, lin_acc, rot_acc, mode == LDO_FAITHFUL_F64);
     }
+    return LD_OK;
+}
+
+int ldo_accelerations_frames(const ld_sim_params *sim, const double angle[3], const double thrust[4],
+                             double lin_acc[3], double rot_acc[3], double rot_matrix[9], int lab_frame)
+{
+    if (!sim || !angle || !thrust || !lin_acc || !rot_acc) return LD_ERR_NULL;
+    accel_faithful_frames(sim, angle, thrust, lin_acc, rot_acc, rot_matrix, lab_frame);
     return LD_OK;
 }
 

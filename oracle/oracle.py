@@ -73,6 +73,18 @@ def accelerations(sim: SimParams, angle, thrust, mode=FAITHFUL_F64):
     return lin, rot
 
 
+def accelerations_frames(sim: SimParams, angle, thrust, lab_frame: bool):
+    """calculate_accelerations with lin_acc_drone_2_lab = lab_frame: (lin [n,3], rot [n,3], Rot [n,3,3])."""
+    angle, thrust = np.atleast_2d(_d(angle)), np.atleast_2d(_d(thrust))
+    n = len(angle)
+    lin, rot, mat = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros((n, 9))
+    for i in range(n):
+        _check(lib().ldo_accelerations_frames(C.byref(sim), _p(angle[i], C.c_double), _p(thrust[i], C.c_double),
+                                              _p(lin[i], C.c_double), _p(rot[i], C.c_double), _p(mat[i], C.c_double),
+                                              1 if lab_frame else 0), "ldo_accelerations_frames")
+    return lin, rot, mat.reshape(n, 3, 3)
+
+
 def measure(sim: SimParams, ep: EpisodeParams, state, acc, thrust, mode=FAITHFUL_F64):
     """Returns (state', acc', reward_delta, crashed) for [n] drones."""
     state, acc, thrust = _d(state).reshape(-1, 12).copy(), _d(acc).reshape(-1, 6).copy(), _d(thrust).reshape(-1, 4)

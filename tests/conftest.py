@@ -67,6 +67,11 @@ def g7():
     return load_golden("g7_flags.npz")
 
 
+@pytest.fixture(scope="session")
+def g8():
+    return load_golden("g8_frames.npz")
+
+
 @pytest.fixture
 def generic_kernels():
     """generic_kernels(True) routes every layer spec to the run-time-spec kernels (ld_debug_force_generic);

@@ -26,6 +26,7 @@ row-major ``(n_out, n_in + 1)`` matrix, layers concatenated):
   g5_events.npz    reward-event KATs: tiny ``fly()`` episodes straddling thresholds
   g6_ga.npz        GA operator KATs under ``np.random.seed``
   g7_flags.npz     ``fly()`` keyword variants: punish_time / reward_time / delta_t / timesteps
+  g8_frames.npz    ``calculate_accelerations`` with lin_acc_drone_2_lab True AND False, + ``self.Rot``
 """
 import os
 import subprocess
@@ -442,9 +443,45 @@ def make_g7():
                         args=np.array([c[1] for c in cases], float), final=np.array([c[2] for c in cases], float))
 
 
+# --------------------------------------------------------------------------- G8
+def make_g8():
+    """calculate_accelerations in BOTH frames (physical_model.py:75-122): lin_acc_drone_2_lab=False returns the
+    body-frame pair (forces / m in float32, moments * 1/I) before Rot^T / Tr are applied (:117-120), and the call
+    leaves the rotation matrix in self.Rot (:90).  Default parameters with wind, and the payload set of G1."""
+    rng = np.random.default_rng(8008)
+    m = 300
+    out = {}
+    for tag, qp in (("plain", QuadcopterPhysics(
+                        mass_center=P.mass_center, mass_motor=P.mass_motor, radius_motor_center=P.radius_motor_center,
+                        coef_force=P.coef_force, coef_moment=P.coef_moment, coef_wind=P.coef_wind, gravity=P.gravity,
+                        I_x=P.I_x, I_y=P.I_y, I_z=P.I_z)),
+                    ("payload", QuadcopterPhysics(
+                        mass_center=P.mass_center, mass_motor=P.mass_motor, radius_motor_center=P.radius_motor_center,
+                        coef_force=P.coef_force, coef_moment=P.coef_moment, coef_wind=P.coef_wind, gravity=P.gravity,
+                        mass_payload=0.12, x_payload=0.03, y_payload=-0.02, I_x=2500e-6, I_y=2300e-6, I_z=4400e-6))):
+        ang = rng.uniform(-1.3, 1.3, (m, 3)); ang[::7] = rng.uniform(-np.pi, np.pi, (len(ang[::7]), 3))
+        u = rng.uniform(0, 1, (m, 4)); w = rng.normal(0, 2, (m, 3)); w[: m // 3] = 0
+        lab_lin, lab_rot, body_lin, body_rot = np.zeros((m, 3)), np.zeros((m, 3)), np.zeros((m, 3)), np.zeros((m, 3))
+        rot = np.zeros((m, 3, 3))
+        for i in range(m):
+            lin, ra = qp.calculate_accelerations(col(ang[i]), col(w[i]), col(u[i]), True)
+            lab_lin[i], lab_rot[i] = lin.ravel(), ra.ravel()
+            lin, ra = qp.calculate_accelerations(col(ang[i]), col(w[i]), col(u[i]), False)
+            body_lin[i], body_rot[i] = np.asarray(lin, np.float64).ravel(), np.asarray(ra, np.float64).ravel()
+            rot[i] = np.asarray(qp.Rot, np.float64)
+        out.update({f"{tag}_angle": ang, f"{tag}_thrust": u, f"{tag}_wind": w, f"{tag}_lab_lin": lab_lin,
+                    f"{tag}_lab_rot": lab_rot, f"{tag}_body_lin": body_lin, f"{tag}_body_rot": body_rot, f"{tag}_Rot": rot})
+    out["payload_params"] = np.array([0.12, 0.03, -0.02, 2500e-6, 2300e-6, 4400e-6])
+    np.savez_compressed(HERE / "g8_frames.npz", **out)
+    print("g8: body-frame accelerations", out["plain_body_lin"][0], out["plain_body_rot"][0])
+
+
 if __name__ == "__main__":
     if "--only-g7" in sys.argv:
         make_g7()
+        sys.exit(0)
+    if "--only-g8" in sys.argv:
+        make_g8()
         sys.exit(0)
     make_g1()
     make_g2()
@@ -453,5 +490,6 @@ if __name__ == "__main__":
     make_g5()
     make_g6()
     make_g7()
+    make_g8()
     sizes = {p.name: p.stat().st_size for p in sorted(HERE.glob("*.npz"))}
     print("written:", sizes, "total", sum(sizes.values()))

@@ -22,6 +22,57 @@ def test_fly_returns_reference_tuple(g3):
         assert d.position.shape == (3, 1) and d.thrust.shape == (4, 1)
 
 
+def test_foreign_controller_and_foreign_drone_plug_in(g3):
+    """north_star: "evolve/brain.py controllers plug in unchanged".  The reference's contract for a controller is an
+    object with a .weights list (evolve/brain.py:10-24, drone/drone.py:65,83-86) and for a drone the public attributes
+    of drone/drone.py:32-76: a bare class carrying only .weights on this package's Drone, and a bare drone-shaped
+    object that is not this package's class at all, both fly to the reference's golden (reward, real_time, idx)."""
+    from learning_drones_amd.drone.drone import Drone
+    from learning_drones_amd.evolve.brain import NeuralNetwork
+    from learning_drones_amd.flight import fly
+
+    class BareController:                                    # nothing but the weights
+        def __init__(self, weights):
+            self.weights = weights
+
+    class BareSensor:
+        def __init__(self):
+            self.current_acceleration = 0.0
+            self.last_acceleration = 0.0
+            self.previous_pos = 0.0
+            self.previous_vel = 0.0
+
+    class BareDrone:                                         # drone/drone.py:32-76, public attributes only
+        def __init__(self, controller):
+            self.controller = controller
+            self.position = np.array([[0.0], [0.0], [10.0]])
+            self.velocity, self.angle, self.angle_vel = np.zeros((3, 1)), np.zeros((3, 1)), np.zeros((3, 1))
+            self.thrust = np.zeros((4, 1))
+            self.sensors = [BareSensor() for _ in range(6)]
+            self.reward, self.coins, self.flight_time, self.crashed = 0, 0, 0, False
+            self.distance_to_coin = np.inf
+
+    for seed in (0, 2, 9):
+        np.random.seed(seed)
+        weights = NeuralNetwork(layer_spec={1: 10, 2: 10, 3: 4}).weights      # the draw Drone() makes (drone.py:65)
+        fin = g3[f"final_{seed}"]
+        d = Drone(visualize=False, n_servers=0)
+        d.controller = BareController([w.copy() for w in weights])
+        reward, real_time, idx = fly(d, timesteps=2500, idx=3)
+        assert (reward, idx) == (int(fin[0]), 3) and abs(real_time - fin[1]) < 1e-12
+        assert (d.coins, d.flight_time, d.crashed) == (int(fin[2]), int(fin[3]), bool(fin[4]))
+        b = BareDrone(BareController([w.copy() for w in weights]))
+        reward, real_time, idx = fly(b, timesteps=2500, idx=4)
+        assert (reward, idx) == (int(fin[0]), 4) and abs(real_time - fin[1]) < 1e-12
+        assert (b.coins, b.flight_time, b.crashed) == (int(fin[2]), int(fin[3]), bool(fin[4]))
+        assert abs(b.distance_to_coin - fin[5]) < 1e-8
+        assert np.allclose(b.position.ravel(), g3[f"state_{seed}"][-1, :3], rtol=1e-8, atol=1e-10)
+        assert b.position.shape == (3, 1) and b.thrust.shape == (4, 1)
+    with pytest.raises(TypeError):
+        d.controller = object()
+        fly(d, timesteps=10)
+
+
 def test_manual_loop_with_measure_and_controller(g3):
     """Drive the reference's loop body by hand through Drone.measure / translate_input_to_thrust."""
     from learning_drones_amd.drone.drone import Drone

@@ -248,7 +248,12 @@ def test_no_fused_step_kernel_runs_out_of_scratch():
     repo = Path(__file__).resolve().parent.parent
     out = subprocess.run([sys.executable, str(repo / "scripts" / "audit_scratch.py")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
-    assert "fly_split_kernel<float, false, 4, 1, true, 32, 32>" in out.stdout and "fly_split_kernel<float, false, 8, 2, false, 32, 32>" in out.stdout
+    assert "fly_split_kernel<float, false, 4, 1, true, 0, 32, 32>" in out.stdout and "fly_split_kernel<float, false, 8, 2, false, 0, 32, 32>" in out.stdout
+    # the variants that keep 136 KiB of a workgroup's genes in LDS: none of those the launch policy picks uses scratch
+    for spec in ("32, 32", "16, 16", "24, 24", "16", "32"):
+        for geometry in ("8, 1, true", "8, 2, true", "8, 4, true", "8, 2, false"):
+            line = [l for l in out.stdout.splitlines() if l.startswith(f"fly_split_kernel<float, false, {geometry}, 136, {spec}>")]
+            assert len(line) == 1 and line[0].endswith("scratch 0"), (spec, geometry, line)
     assert "fly_resident_kernel" in out.stdout
 
 
@@ -259,7 +264,15 @@ def test_build_flags_per_translation_unit():
     from learning_drones_amd import build as B
     no_sink = "-simplifycfg-sink-common=false"
     for name, want in (("ld_split_10_10.hip", True), ("ld_split_8_8.hip", True), ("ld_split_8_10.hip", True), ("ld_split_16.hip", False),
-                       ("ld_split_32_32.hip", False), ("ld_split_64_64_64_W8.hip", False), ("ld_resident.hip", False), ("ld_abi.hip", False)):
+                       ("ld_split_32_32.hip", False), ("ld_split_64_64_64_W8.hip", False), ("ld_resident.hip", False), ("ld_abi.hip", False),
+                       # the LDS-keeping variants live in translation units of their own, always built without the sinking
+                       ("ld_split_keep_32_32.hip", True), ("ld_split_keep_16.hip", True), ("ld_split_keep_64.hip", True)):
         assert (no_sink in B.flags_for(Path(name))) is want, name
+    assert B.keeps_in_lds((32, 32)) and B.keeps_in_lds((12, 12)) and not B.keeps_in_lds((48, 48)) and not B.keeps_in_lds((64, 64, 64))
+    # ... one per shipped layer spec of up to 512 gene words, and the main unit of each of those specs calls it
+    for src in B.SOURCES:
+        if src.name.startswith("ld_split_keep_"):
+            main = src.with_name(src.name.replace("ld_split_keep_", "ld_split_"))
+            assert "LD_SPLIT_KEEP_TU" in src.read_text() and "LD_SPLIT_HAS_KEEP" in main.read_text(), src.name
     assert B.narrow((12, 12)) and B.narrow((13, 7)) and not B.narrow((20, 20)) and not B.narrow((16,))
     assert "-ffp-contract=off" in B.FLAGS and "-fno-slp-vectorize" in B.FLAGS

@@ -60,6 +60,28 @@ def test_payload_physics(oracle, g1):
         assert np.array_equal(rot[0], g1["payload_rot_acc"][i])
 
 
+def frames_sim(g8, tag):
+    if tag == "plain":
+        return SimParams.reference()
+    pp = g8["payload_params"]
+    return SimParams.reference(mass_payload=pp[0], x_payload=pp[1], y_payload=pp[2], I_x=pp[3], I_y=pp[4], I_z=pp[5])
+
+
+def test_accelerations_in_both_frames(oracle, g8):
+    """calculate_accelerations(lin_acc_drone_2_lab=False) and the self.Rot it leaves behind
+    (physical_model.py:90, :114-120), bit for bit, next to the lab-frame pair of the same inputs."""
+    for tag in ("plain", "payload"):
+        sim = frames_sim(g8, tag)
+        for i in range(len(g8[f"{tag}_angle"])):
+            sim.wind[:] = list(g8[f"{tag}_wind"][i])
+            lin, rot, mat = oracle.accelerations_frames(sim, g8[f"{tag}_angle"][i], g8[f"{tag}_thrust"][i], False)
+            assert np.array_equal(lin[0], g8[f"{tag}_body_lin"][i]) and np.array_equal(rot[0], g8[f"{tag}_body_rot"][i])
+            assert np.array_equal(mat[0], g8[f"{tag}_Rot"][i])
+            lin, rot, mat = oracle.accelerations_frames(sim, g8[f"{tag}_angle"][i], g8[f"{tag}_thrust"][i], True)
+            assert np.array_equal(lin[0], g8[f"{tag}_lab_lin"][i]) and np.array_equal(rot[0], g8[f"{tag}_lab_rot"][i])
+            assert np.array_equal(mat[0], g8[f"{tag}_Rot"][i])
+
+
 def test_closed_forms_agree_with_reference_step(oracle, g1):
     """The closed-form accelerations (what the f32 kernel computes) are the same function."""
     sim, ep = SimParams.reference(), EpisodeParams.reference()

@@ -7,8 +7,9 @@
 
 Workload (BASELINE config 3, the one the metric is quoted on): 65 536 drones per GPU x 2 000
 timesteps, 15-32-32-4 controller, 3-coin chain, crash penalty on, float32.  A "step" is one whole
-episode of the population = the fused-step launches of ld_fly_rollout_f32 (four tiles of 16 384 drones, 64
-timesteps per launch with the drone state in registers in between: 128 launches) + the finalize launch (+ the RCCL all-gather of the
+episode of the population = the fused-step launches of ld_fly_rollout_f32 (32 launches of 64 timesteps over all
+65 536 drones, the drone state in registers in between; workgroups of 8 wavefronts fly 32 drones each and keep
+136 KiB of their genes in LDS for the launch) + the finalize launch (+ the RCCL all-gather of the
 16-byte fitness records when N > 1).  Population shards are independent, so the headline line is weak
 scaling: every rank owns 65 536 drones.  With N > 1 the same run ALSO times the strong-scaling case
 BASELINE's target describes (ONE 65 536-drone population split over the N GPUs) and reports it in the
@@ -20,9 +21,13 @@ Genomes are synthetic: hover controllers (learning-drones_amd/controllers.py) wi
 noise, so that nearly every drone is alive for all 2 000 steps and every counted drone-step does the
 full work (frozen blocks skip their gene traffic; the JSON line reports the live fraction).
 
-Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events on the launch stream,
-`cpu_baseline` times the CPU oracle (the stand-in for the reference's Python loop) on the host
-cores, rank 0, N = 1 only.
+Rank 0 prints ONE JSON line.  `roofline` prices the headline launch, timed live with HIP events on the launch
+stream, at every level its bytes can come from -- HBM, the Infinity-Cache fabric, the L2s, LDS -- and at the vector
+issue rate, and names the level with the highest fraction `bound` (so `frac` <= 1 by construction); the counter-backed
+levels are read from the rocprofv3 summaries committed under profiles/ for this same configuration.
+`roofline_hbm_bound` is the same kernel family with nothing kept on chip (every timestep's genes from HBM), the figure
+BASELINE's ">= 60 % of the HBM roofline" asks about.  `cpu_baseline` times the CPU oracle (the stand-in for the
+reference's Python loop) on the host cores, rank 0, N = 1 only.
 """
 from __future__ import annotations
 
@@ -39,6 +44,10 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+L2_PEAK_GBS = 34500.0            # MI355X_MICROARCH.md, L2 (per XCD): ~34.5 TB/s aggregate
+LDS_PEAK_GBS = 150000.0          # MI355X_MICROARCH.md, LDS: ~150 TB/s aggregate for ds_read_b64 / b128 with every CU streaming
+FABRIC_PEAK_GBS = 7900.0         # Infinity Cache -> L2 stream: the best a plain reader got on this pool (profiles/r02_mall_read.json)
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2   # wave64 vector instructions per ns, chip-wide: one per 2 cycles per SIMD-32 at 2.4 GHz
 WORKLOAD = dict(drones_per_gpu=65536, timesteps=2000, hidden=(32, 32), n_coins=3)
 
 
@@ -117,6 +126,8 @@ def main():
     ap.add_argument("--no-specialise", dest="specialise", action="store_false", help="stay on the run-time-spec kernels")
     ap.add_argument("--walls", type=int, default=0, help="number of wall boxes (BASELINE config 5 has walls: objects/walls.py is "
                     "empty in the reference, so the boxes are this build's: slabs beside the flight corridor, tested every step, never hit)")
+    ap.add_argument("--no-lds-keep", action="store_true", help="fly without the genes kept in LDS (ld_debug_lds_keep(0)): the rollout "
+                    "then tiles the population for the Infinity Cache; with --tile-drones = --drones every timestep's genes come from HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline rollout and its roofline (for rocprofv3 "
                     "runs: keeps every fused launch in the trace a full, live-population launch of the headline geometry)")
@@ -151,8 +162,11 @@ def main():
         dist.all_reduce(torch.zeros(1, device=device))
         torch.cuda.synchronize()
 
+    from learning_drones_amd import _native
     from learning_drones_amd.parallel import ShardedPopulation
     from learning_drones_amd.params import coin_chain_reference
+    if args.no_lds_keep:
+        _native.lib().ld_debug_lds_keep(0)
     hidden = tuple(int(h) for h in args.hidden.split(","))
     T = args.timesteps
     if args.drones % world and (args.strong or world > 1):
@@ -181,10 +195,12 @@ def main():
                         tile_drones=args.tile_drones or None)
         return {}
 
-    def measure(n_local, steps, warmup, force_tile=None):
+    def measure(n_local, steps, warmup, force_tile=None, keep=None):
         """`steps` timed episodes of a population of n_local drones per rank: barrier + synchronize on both
         sides, wall time = max over ranks; the fused launches' average duration from HIP events on the
-        launch stream over the same region."""
+        launch stream over the same region.  keep=False: without the genes kept in LDS."""
+        if keep is not None:
+            _native.lib().ld_debug_lds_keep(1 if keep else 0)
         pop = ShardedPopulation(n_local * world, hidden, coins=coin_chain_reference(args.coins), precision="f32", walls=walls,
                                 device=device, process_group=dist.group.WORLD if dist else None, specialise=args.specialise)
         assert pop.local.n == n_local
@@ -199,7 +215,7 @@ def main():
             geo.update(steps_per_launch=k, tile_drones=tile, launches=-(-n_local // tile) * -(-T // k))
             # the wavefronts per block the library picks for launches of `tile` drones (or the explicit value)
             geo["waves_per_block"] = args.waves_per_block or pop.local.auto_waves_per_block(tile, k)
-            geo["cached_drones"] = 0                       # an explicit geometry is flown as given: one kernel per launch
+            geo["kept_words"], geo["streamed_words"] = pop.local.kept_words(geo["waves_per_block"], min(k, T))
 
         def episode():
             pop.local.reset()
@@ -217,39 +233,102 @@ def main():
         ev1.record()
         fence()
         dt = max_over_ranks(time.perf_counter() - t0)
+        if keep is not None:
+            _native.lib().ld_debug_lds_keep(0 if args.no_lds_keep else -1)
         launch_ms = ev0.elapsed_time(ev1) / (steps * geo["launches"]) if steps else float("nan")
+        launch_s = launch_ms * 1e-3
         # algorithmic bytes of the AVERAGE launch of the episode: every drone streams its genes T times and reads and
         # writes its state once per launch (the last launch of a tile is shorter when K does not divide T, the last
         # tile smaller when the tile does not divide n: averaging over the episode's launches accounts for both)
         launches_per_tile = -(-T // geo["steps_per_launch"])
-        bytes_per_launch = (pop.local.bytes_per_launch(T, n_local) - pop.local.bytes_per_launch(0, n_local)
-                            + launches_per_tile * pop.local.bytes_per_launch(0, n_local)) / geo["launches"]
-        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "kernel": ("fly_split_kernel<float, L=%d, %s>" % (geo["waves_per_block"], "-".join(map(str, hidden)))
+        state_bytes = pop.local.bytes_per_launch(0, n_local)                  # 200 B per drone, once per launch
+        gene_bytes = pop.local.bytes_per_launch(T, n_local) - state_bytes     # 4P per drone-step, whole episode
+        tiles = -(-n_local // geo["tile_drones"])
+        bytes_per_launch = (gene_bytes + launches_per_tile * state_bytes) / geo["launches"]
+        steps_per_launch_avg = T * tiles / geo["launches"]                    # timesteps of the average launch
+        drones_per_launch_avg = n_local / tiles
+        # where the average launch's gene bytes come from.  A gene word is 16 bytes; the launch keeps `kept_words` per drone
+        # in LDS (read from memory once per launch, from LDS every timestep) and requests `streamed_words` per drone and
+        # timestep from the L2s, which pass on to the fabric / HBM what they do not hold.
+        kept, streamed = geo["kept_words"], geo["streamed_words"]
+        lds_bytes = drones_per_launch_avg * steps_per_launch_avg * 16 * kept
+        l2_request_bytes = drones_per_launch_avg * (steps_per_launch_avg * 16 * streamed + 16 * kept) + state_bytes / tiles
+        # HBM, modelled: a launch's genes are new to the caches when they exceed the Infinity Cache between two launches
+        # over the same drones (the next launch of a tile comes right behind it; of the whole population, after 446 MB)
+        tile_gene_bytes = drones_per_launch_avg * 4 * pop.local.P
+        hbm_bytes = (tile_gene_bytes if tile_gene_bytes > 200e6 else tile_gene_bytes / launches_per_tile) + state_bytes / tiles
+        if steps_per_launch_avg < 2 and tile_gene_bytes > 200e6:
+            hbm_bytes = bytes_per_launch                                      # one timestep per launch: everything from HBM
+        levels = {
+            "hbm": {"bytes_per_launch": hbm_bytes, "source": "model: a launch's genes from HBM once (they exceed the Infinity Cache "
+                    "between launches) + the state", "achieved": hbm_bytes / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"},
+            "l2": {"bytes_per_launch": l2_request_bytes, "source": "model: the words the launch does not keep in LDS, requested "
+                   "from the L2s every timestep (+ the kept words once)", "achieved": l2_request_bytes / launch_s / 1e9,
+                   "peak": L2_PEAK_GBS, "unit": "GB/s"},
+            "lds": {"bytes_per_launch": lds_bytes, "source": "model: the kept words, read back from LDS every timestep",
+                    "achieved": lds_bytes / launch_s / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s"},
+        }
+        roof = {"kernel": ("fly_split_kernel<float, %d wavefronts per block, %s KiB of genes kept in LDS, %s>"
+                           % (geo["waves_per_block"], "136" if kept else "0", "-".join(map(str, hidden)))
                            if geo["steps_per_launch"] > 1 or geo["waves_per_block"] > 1 or pop.local.has_resident_engine()
                            else "fly_step_kernel<float, GenericNet> (run-time layer spec)"),
-                "bytes_per_launch": bytes_per_launch, "launch_us": launch_ms * 1e3,
+                "launch_us": launch_ms * 1e3, "bytes_per_launch": bytes_per_launch, "algorithmic_gbs": bytes_per_launch / launch_s / 1e9,
                 "timesteps_per_launch": geo["steps_per_launch"], "wavefronts_per_block": geo["waves_per_block"],
-                "launches_per_episode": geo["launches"], "drones_per_launch": geo["tile_drones"],
-                "cached_drones_per_launch": geo.get("cached_drones", 0),
-                "tiles": -(-n_local // geo["tile_drones"]),
-                "launch_note": ("a launch here = two concurrent kernels: the first %d drones of the tile by fly_split_kernel<L=8, two "
-                                "workgroups per block, CACHEABLE gene loads> on the library's side stream, the rest by the streaming "
-                                "kernel named above; launch_us = HIP-event time of the episode / launches" % geo.get("cached_drones", 0))
-                               if geo.get("cached_drones", 0) else None,
-                "tiling_note": "a population whose genes exceed the 256 MiB Infinity Cache is flown tile by tile (a tile's whole "
-                               "episode, then the next tile): the genes, re-streamed every timestep, then come from HBM once per "
-                               "episode and from the cache afterwards, so `achieved` (algorithmic bytes / time) can exceed the HBM "
-                               "peak; `traffic` is what the memory-side counters saw",
-                "bytes_model": "per launch, averaged over the episode's launches: drones x (timesteps x 4P + 200): genes once per "
-                               "timestep, the 25 state words read and written once per launch (they stay in registers in between); "
-                               "4P + 200 per drone-step at one timestep per launch"}
+                "launches_per_episode": geo["launches"], "drones_per_launch": geo["tile_drones"], "tiles": tiles,
+                "kept_words_per_drone": kept, "streamed_words_per_drone": streamed,
+                "levels": levels,
+                "bytes_model": "algorithmic bytes per launch, averaged over the episode's launches: drones x (timesteps x 4P + 200): "
+                               "genes once per timestep, the 25 state words read and written once per launch (they stay in registers "
+                               "in between); 4P + 200 per drone-step at one timestep per launch.  algorithmic_gbs is that over the "
+                               "launch time: what an implementation that fetched every gene from memory every timestep would have to "
+                               "stream; the launch serves most of it on chip, so it is NOT priced against a memory ceiling -- "
+                               "`levels` is"}
         return pop, records, dt, roof
+
+    def close_roofline(roof, n_drones):
+        """Add the counter-backed levels from the committed profile of this configuration (profiles/r*_pmc.json: they
+        cannot be collected inside this run), then name the binding level."""
+        for f in sorted((REPO / "profiles").glob("r*_pmc.json"), reverse=True):
+            prof = json.loads(f.read_text())
+            cfg = prof.get("config")
+            if not cfg or "per_launch" not in prof:
+                continue
+            if (cfg["drones"] == n_drones and tuple(cfg["hidden"]) == hidden and cfg["coins"] == args.coins
+                    and cfg.get("timesteps_per_launch", 1) == roof["timesteps_per_launch"]
+                    and cfg.get("wavefronts_per_block", 1) == roof["wavefronts_per_block"]
+                    and cfg.get("drones_per_launch", cfg["drones"]) == roof["drones_per_launch"]
+                    and cfg.get("kept_words_per_drone", 0) == roof["kept_words_per_drone"]):
+                per, launch_s = prof["per_launch"], roof["launch_us"] * 1e-6
+                roof["counters_source"] = f"profiles/{f.name}"
+                roof["launch_us_profiled"] = prof.get("launch_us_profiled")
+                if per.get("fabric_bytes") is not None:
+                    roof["levels"]["fabric"] = {"bytes_per_launch": per["fabric_bytes"], "source": "PMC: 2 x FETCH_SIZE + WRITE_SIZE (gfx950 "
+                                                "correction), the L2s' memory side: Infinity-Cache hits included", "achieved":
+                                                per["fabric_bytes"] / launch_s / 1e9, "peak": FABRIC_PEAK_GBS, "unit": "GB/s"}
+                    roof["traffic"] = per["fabric_bytes"]
+                if per.get("l2_hit_rate") is not None:
+                    roof["levels"]["l2"]["hit_rate_pmc"] = per["l2_hit_rate"]
+                if per.get("valu_wave_instructions") is not None:
+                    roof["levels"]["valu_issue"] = {"wave_instructions_per_launch": per["valu_wave_instructions"], "source": "PMC: SQ_INSTS_VALU",
+                                                    "achieved": per["valu_wave_instructions"] / launch_s / 1e9, "peak": VALU_PEAK_GINST,
+                                                    "unit": "G wave-instructions/s"}
+                for key in ("sq_busy_fraction", "sq_issue_fraction", "sq_wait_fraction"):
+                    if per.get(key) is not None:
+                        roof[key] = per[key]
+                break
+        roof.setdefault("traffic", None)
+        for lv in roof["levels"].values():
+            lv["frac"] = lv["achieved"] / lv["peak"]
+        name = max(roof["levels"], key=lambda k: roof["levels"][k]["frac"])
+        top = roof["levels"][name]
+        roof.update(bound={"hbm": "hbm", "fabric": "infinity-cache fabric", "l2": "l2", "lds": "lds", "valu_issue": "valu issue"}[name],
+                    achieved=top["achieved"], peak=top["peak"], unit=top["unit"], frac=top["frac"])
+        return roof
 
     n_total_strong = args.drones
     n_local = args.drones // world if args.strong else args.drones
     pop, records, dt, roof = measure(n_local, args.steps, args.warmup)
+    roof = close_roofline(roof, n_local)
 
     # proof that the collective saw every rank: the ranks themselves, gathered, and a checksum of the
     # gathered records (identical on every rank by construction; rank 0 prints it)
@@ -274,7 +353,8 @@ def main():
         pop_s, rec_s, dt_s, roof_s = measure(n_total_strong // world, args.steps, 1)
         strong = {"value": n_total_strong * T * args.steps / dt_s, "unit": "drone-steps/s", "scaling": "strong",
                   "population": n_total_strong, "drones_per_gpu": n_total_strong // world, "ms_per_step": dt_s / args.steps * 1e3,
-                  "roofline": roof_s, "records": {"rows": int(rec_s.shape[0]), "checksum": checksum(rec_s)}}
+                  "roofline": close_roofline(roof_s, n_total_strong // world),
+                  "records": {"rows": int(rec_s.shape[0]), "checksum": checksum(rec_s)}}
         del pop_s
 
     extras = {}
@@ -290,9 +370,11 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 400 * 1e3
-        extras["one_timestep_per_launch"] = {"launch_us": us, "achieved": pop.local.bytes_per_launch(1) / us / 1e3, "unit": "GB/s",
-                                             "frac": pop.local.bytes_per_launch(1) / us / 1e3 / HBM_PEAK_GBS,
-                                             "bytes_per_launch": pop.local.bytes_per_launch(1)}
+        extras["one_timestep_per_launch"] = {"launch_us": us, "bound": "hbm", "achieved": pop.local.bytes_per_launch(1) / us / 1e3, "peak": HBM_PEAK_GBS,
+                                             "unit": "GB/s", "frac": pop.local.bytes_per_launch(1) / us / 1e3 / HBM_PEAK_GBS,
+                                             "bytes_per_launch": pop.local.bytes_per_launch(1),
+                                             "note": "ld_fly_step_f32: the literal contract, one launch advances the whole population one "
+                                                     "timestep; nothing can be kept on chip, every gene comes from HBM every launch"}
         # Practical ceiling next to the spec peak: a device-to-device copy of 1 GiB on this GPU
         src_buf = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=device).normal_()
         dst_buf = torch.empty_like(src_buf)
@@ -307,22 +389,35 @@ def main():
         roof["copy_ceiling_gbs"] = 10 * 2 * src_buf.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del src_buf, dst_buf
 
-    # The same population in whole-population launches: every timestep's genes from HBM (the HBM-bound figure next
-    # to the cache-blocked headline), when the headline run was tiled
-    if not args.no_extras and roof["tiles"] > 1:
-        _, _, dt_w, roof_w = measure(n_local, args.steps, 1, force_tile=n_local)
-        extras["whole_population_launches"] = {"value": n_local * world * T * args.steps / dt_w, "unit": "drone-steps/s",
-                                               "ms_per_step": dt_w / args.steps * 1e3,
-                                               "roofline": {k: roof_w[k] for k in ("achieved", "frac", "launch_us", "bytes_per_launch",
-                                                                                   "timesteps_per_launch", "wavefronts_per_block",
-                                                                                   "drones_per_launch", "launches_per_episode")}}
+    # The HBM-bound form of the same kernel family: 64 timesteps per launch over the whole population with NOTHING kept on
+    # chip (no genes in LDS, no tiles for the Infinity Cache), so every timestep's genes come from HBM -- what BASELINE's
+    # ">= 60 % of the HBM roofline on the fused step kernel" asks about.  And the round-2 rollout (Infinity-Cache tiles,
+    # nothing kept in LDS) for comparison.
+    hbm_bound = None
+    if not args.no_extras and roof["kept_words_per_drone"] > 0 and 4 * pop.local.P * n_local > 300e6:
+        _, _, dt_w, roof_w = measure(n_local, args.steps, 1, force_tile=n_local, keep=False)
+        hbm_bound = {"bound": "hbm", "achieved": roof_w["algorithmic_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": roof_w["algorithmic_gbs"] / HBM_PEAK_GBS, "launch_us": roof_w["launch_us"], "bytes_per_launch": roof_w["bytes_per_launch"],
+                     "kernel": roof_w["kernel"], "timesteps_per_launch": roof_w["timesteps_per_launch"],
+                     "wavefronts_per_block": roof_w["wavefronts_per_block"], "drones_per_launch": roof_w["drones_per_launch"],
+                     "value": n_local * world * T * args.steps / dt_w, "ms_per_step": dt_w / args.steps * 1e3,
+                     "note": "the same fused step with nothing kept on chip: whole-population launches (446 MB of genes, re-streamed "
+                             "from HBM every timestep), ld_debug_lds_keep(0); algorithmic bytes / HIP-event launch time against the HBM peak"}
+        close_roofline(roof_w, n_local)
+        hbm_bound["traffic"] = roof_w.get("traffic")
+        hbm_bound["counters_source"] = roof_w.get("counters_source")
+        _, _, dt_t, roof_t = measure(n_local, args.steps, 1, keep=False)
+        extras["without_kept_genes"] = {"value": n_local * world * T * args.steps / dt_t, "unit": "drone-steps/s", "ms_per_step": dt_t / args.steps * 1e3,
+                                        "launch_us": roof_t["launch_us"], "drones_per_launch": roof_t["drones_per_launch"],
+                                        "wavefronts_per_block": roof_t["wavefronts_per_block"], "algorithmic_gbs": roof_t["algorithmic_gbs"],
+                                        "note": "the round-2 rollout: tiles of ~112 MB of genes that the Infinity Cache holds, nothing in LDS"}
 
     # The shard one GPU owns when BASELINE's 65 536-drone population is spread over 8 (N = 1 only: with
     # N > 1 the strong_scaling object measures the real thing)
     if world == 1 and not args.no_extras and n_local == WORKLOAD["drones_per_gpu"]:
         _, _, dt_8, roof_8 = measure(n_local // 8, args.steps, 1)
         extras["shard_of_8"] = {"drones": n_local // 8, "value": n_local // 8 * T * args.steps / dt_8, "unit": "drone-steps/s",
-                                "ms_per_step": dt_8 / args.steps * 1e3, "roofline": roof_8}
+                                "ms_per_step": dt_8 / args.steps * 1e3, "roofline": close_roofline(roof_8, n_local // 8)}
 
     # The reference's own kind of population (random genomes, evolve/brain.py:24): every drone tumbles
     # and crashes within a few hundred steps; frozen blocks skip their gene traffic, so an episode
@@ -341,26 +436,6 @@ def main():
     if engines:
         random_pop["live_drone_step_fraction"] = float(rec[:, 1].double().sum().item()) / (rec.shape[0] * T)
         pop.local.set_genomes(make_genomes(torch, n_local, hidden, device, seed=rank))
-
-    # HBM bytes per launch from the PMC counters and the profiled launch duration: collected by separate
-    # rocprofv3 passes of this same command and committed under profiles/ (they cannot be read live);
-    # used only when the profiled launch configuration is the one being run.
-    for f in sorted((REPO / "profiles").glob("r*_pmc.json"), reverse=True):
-        prof = json.loads(f.read_text())
-        cfg = prof.get("config")
-        if not cfg or "hbm_traffic_bytes_per_launch" not in prof:
-            continue
-        if (cfg["drones"] == n_local and tuple(cfg["hidden"]) == hidden and cfg["coins"] == args.coins
-                and cfg.get("timesteps_per_launch", 1) == roof["timesteps_per_launch"]
-                and cfg.get("wavefronts_per_block", 1) == roof["wavefronts_per_block"]
-                and cfg.get("drones_per_launch", cfg["drones"]) == roof["drones_per_launch"]
-                and cfg.get("cached_drones_per_launch", 0) == roof["cached_drones_per_launch"]):
-            roof["traffic"], roof["traffic_source"] = prof["hbm_traffic_bytes_per_launch"], f"profiles/{f.name}"
-            if prof.get("launch_us_profiled"):
-                roof["launch_us_profiled"] = prof["launch_us_profiled"]
-                roof["frac_profiled"] = roof["bytes_per_launch"] / prof["launch_us_profiled"] / 1e3 / HBM_PEAK_GBS
-            break
-    roof.setdefault("traffic", None)
 
     # The genome-resident engine (one launch per episode, genes held in registers: beyond the contract
     # of streaming the genes every timestep, bit-identical results) on the same workload, for reference.
@@ -455,11 +530,14 @@ def main():
                            "device select+breed (evolve/util.py + Drone.mutate semantics), reset; rollout engine: "
                            + evo.engine + " (work-queue resident kernel where available)"
                            + ", parent exchange: " + (evo.exchange if world > 1 else "local"),
+                           "exchange": evo.exchange if world > 1 else "local",
+                           "exchange_bytes_per_generation_per_rank": evo.exchange_bytes(),
                            "live_drone_step_fraction": gen_live, "error": gen_error,
                            "select_breed_ms": breed_ms, "select_breed_gbs": breed_gbs,
                            "select_breed_note": "gather of 16-byte parent words at random drone indices + streaming "
                                                 "child stores; algorithmic 8P bytes per drone"},
             "roofline": roof,
+            "roofline_hbm_bound": hbm_bound,
         }
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:

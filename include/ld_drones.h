@@ -13,12 +13,20 @@
  *   - extern "C", plain pointers and sizes, POD structs passed by pointer and
  *     copied; no C++/torch types, no exceptions across the boundary.
  *   - Every array pointer is a DEVICE pointer owned by the caller (e.g. a
- *     PyTorch-ROCm tensor's data_ptr()); the library allocates nothing and
- *     keeps no global state (the ld_debug_* test hook aside).  Structs live in
- *     HOST memory.
+ *     PyTorch-ROCm tensor's data_ptr()); the library allocates no device memory,
+ *     creates no streams or events, and launches on the caller's stream only.
+ *     Structs live in HOST memory.
+ *   - State the library keeps (all of it; none is per-population):
+ *       process-wide  the two ld_debug_* switches (atomics) and the registry of
+ *                     run-time specialisations (ld_register_specialisation_f32:
+ *                     append-only, mutex-guarded writes, lock-free reads);
+ *       per thread    the text behind ld_last_hip_error().
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
- *     Kernels are enqueued and NOT synchronised; functions are re-entrant.
- *     One population must not be stepped from two streams at once.
+ *     Kernels are enqueued and NOT synchronised; functions are re-entrant and
+ *     may be called from any number of host threads and streams at once (each
+ *     launch follows its stream's device).  One population must not be stepped
+ *     from two streams at once.  Everything an entry point enqueues is ordered
+ *     on `stream`, so a whole episode can be captured into a HIP graph.
  *   - Return value: LD_OK (0) or a negative ld_status; ld_strerror() names it.
  *   - Population arrays are struct-of-arrays over the drone index (lane i of a
  *     wavefront owns drone i):
@@ -53,7 +61,7 @@
 extern "C" {
 #endif
 
-#define LD_ABI_VERSION 2
+#define LD_ABI_VERSION 3
 #define LD_N_INPUTS 15          /* evolve/brain.py:10 n_inputs: pos, vel, angle, angle_vel, coin */
 #define LD_N_OUTPUTS 4          /* four rotor thrust fractions */
 #define LD_MAX_HIDDEN_LAYERS 4
@@ -213,6 +221,18 @@ int ld_accelerations_f32(const ld_sim_params *sim, const float *angle, const flo
 int ld_accelerations_f64(const ld_sim_params *sim, const double *angle, const double *thrust,
                          double *lin_acc, double *rot_acc, int64_t n, void *stream);
 
+/* The same call with the reference's lin_acc_drone_2_lab argument and its side effect on self.Rot
+ * (physical_model.py:75-90,:114-120): lab_frame != 0 is ld_accelerations_*; lab_frame == 0 returns the pair of
+ * :114-115 in the drone's frame -- lin_acc = forces / m (the reference keeps it in float32; _f64 returns that value),
+ * rot_acc = (moments + payload moments) * 1/I -- before Rot^T and the Euler-rate matrix Tr are applied (:117-120).
+ * rot_matrix: Real[9][n], the row-major entries of self.Rot = (Rz Ry Rx)^T as the call leaves it (:90), or NULL. */
+int ld_accelerations_frames_f32(const ld_sim_params *sim, const float *angle, const float *thrust,
+                                float *lin_acc, float *rot_acc, float *rot_matrix, int32_t lab_frame,
+                                int64_t n, void *stream);
+int ld_accelerations_frames_f64(const ld_sim_params *sim, const double *angle, const double *thrust,
+                                double *lin_acc, double *rot_acc, double *rot_matrix, int32_t lab_frame,
+                                int64_t n, void *stream);
+
 /* Replaces NeuralNetwork.feed_forward (evolve/brain.py:41-54) for n independent genomes:
  * inputs Real[LD_N_INPUTS][n], outputs Real[LD_N_OUTPUTS][n]. */
 int ld_mlp_forward_f32(const ld_mlp_spec *spec, const float *genomes, const float *inputs,
@@ -237,16 +257,20 @@ int ld_fly_step_f64(const ld_sim_params *sim, const ld_episode_params *ep, const
  * waves_per_block 0 or 1, anything else returns LD_ERR_SPEC; ld_fly_steps_f64 is that kernel too): the 64 drones
  * of a genome block are served by `waves_per_block` wavefronts (1, 2, 4, 8: one workgroup of that many;
  * 16, 32: two / four workgroups of 8, each flying 32 / 16 of the block's drones; nets wider than 512
- * gene words: 8, 16 = two / four workgroups of 4, 32 not available; 0 = chosen from n, the spec and
- * n_steps).  Each wavefront of a workgroup streams a contiguous share of every layer's rows (still one
+ * gene words: 8, 16 = two / four workgroups of 4, 32 not available; 11 = workgroups of 8 wavefronts flying 48
+ * consecutive drones each, gene-keeping launches only; 0 = chosen from n, the spec and n_steps).  Each wavefront of a workgroup streams a contiguous share of every layer's rows (still one
  * lane per drone, one coalesced line per gene word, every neuron's sum in gene order), the layers'
  * outputs cross wavefronts through LDS.  Small shards need this to fill the chip: 8 192 drones are 128
  * wavefronts at one wavefront per block, and 128 workgroups on 256 CUs at one workgroup per block.
  * With n_steps > 1 the drone
  * state stays in registers between timesteps and the genes are re-streamed every step (from L2 /
  * Infinity Cache when the shard's genomes fit there): no per-step kernel boundary and 200/n_steps
- * instead of 200 bytes of state traffic per drone-step.  Results are bit-identical to n_steps calls
- * of ld_fly_step_f32 for every waves_per_block.  ld_fly_step_f32 itself is
+ * instead of 200 bytes of state traffic per drone-step.  With n_steps >= 8, for nets of up to 512 gene words whose
+ * hidden layers split evenly over 8 wavefronts, the workgroups of 8 wavefronts (waves_per_block 8, 11, 16, 32)
+ * also KEEP 136 KiB of their drones' genes in the CU's LDS for the whole launch (loaded once, read back from LDS
+ * every timestep: 32 / 43 / 64 / 100 % of a 32-32 net's genes at 64 / 48 / 32 / 16 drones per workgroup), so only
+ * the rest is re-streamed; ld_fly_steps_kept_words_f32 reports the split.  Results are bit-identical to n_steps
+ * calls of ld_fly_step_f32 for every waves_per_block, with and without the kept genes.  ld_fly_step_f32 itself is
  * ld_fly_steps_f32(..., 1, 0, stream) for those specs. */
 int ld_fly_steps_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
                      const double *coins, const double *walls, const float *genomes,
@@ -269,10 +293,8 @@ int ld_fly_finalize_f64(const ld_episode_params *ep, const double *coins, const 
  * launch, all enqueued from C (no per-step host round trip); everything is ordered on `stream`: work enqueued
  * on it afterwards sees the finished episode.  64 timesteps per launch, the drone state in registers in between
  * (identical results).  _f64 and the float32 specs without an unrolled specialisation: one wavefront per genome
- * block.  The unrolled float32 specs take ld_fly_rollout_steps_f32's default geometry, and for tiles of
- * >= 16 384 drones the head of each tile is flown concurrently on a side stream the library owns (one per host
- * thread and device, created at first use, forked from and joined to `stream` by events, which also works under
- * stream capture: a whole episode can be captured into a HIP graph and replayed): see ld_fly_rollout_cached_drones_f32. */
+ * block.  The unrolled float32 specs take ld_fly_rollout_steps_f32's default geometry.  Every launch goes to
+ * `stream` (the library owns no stream), so a whole episode can be captured into a HIP graph and replayed. */
 int ld_fly_rollout_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
                        const double *coins, const double *walls, const float *genomes,
                        float *fstate, int32_t *istate, ld_fitness_record *records,
@@ -287,8 +309,11 @@ int ld_fly_rollout_f64(const ld_sim_params *sim, const ld_episode_params *ep, co
  * `waves_per_block` as in ld_fly_steps_f32, and `tile_drones` (a multiple of 64; 0 = the library's
  * choice, n = no tiling): the population is flown tile by tile, a tile's whole episode before the next
  * tile starts, so that a tile's genes -- re-streamed every timestep -- come from HBM once per episode
- * and from the 256 MiB Infinity Cache afterwards.  The library tiles only when the population's genes
- * exceed the cache and at least 16 384 drones' genes fit in ~120 MB (config 3: four tiles of 16 384).
+ * and from the 256 MiB Infinity Cache afterwards.  The library tiles only when the launches do not keep genes
+ * in LDS (ld_fly_steps_f32), the population's genes exceed the cache and at least 16 384 drones' genes fit in
+ * ~120 MB.  Gene-keeping launches are not tiled: 256 workgroups are resident at a time, each flies all its
+ * timesteps before the next takes its CU, and what the resident ones stream fits the L2s whatever the launch
+ * covers (config 3: one launch of 65 536 drones per 64 timesteps, two workgroups of 8 wavefronts per block).
  * Drones are independent, so results do not depend on the tiling.  ld_fly_rollout_f32 is this with
  * (0, 0, 0) for the specs that have an unrolled specialisation; LD_ERR_SPEC for the others. */
 int ld_fly_rollout_steps_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
@@ -304,12 +329,12 @@ int ld_fly_rollout_steps_f32(const ld_sim_params *sim, const ld_episode_params *
 int ld_fly_rollout_geometry_f32(const ld_mlp_spec *spec, int64_t n, int32_t timesteps,
                                 int32_t *steps_per_launch, int32_t *waves_per_block, int32_t *n_launches,
                                 int64_t *tile_drones);
-/* How many drones at the head of each tile ld_fly_rollout_f32 flies with CACHEABLE gene loads, in a second launch
- * on a side stream of its own that it forks from and joins to `stream` (0 = none: the tile is one launch).  The
- * L2s (8 x 4 MB) keep a good part of those drones' genes from timestep to timestep while the rest of the tile
- * streams past them non-temporally; chosen for tiles of >= 16 384 drones of shipped layer specs of up to 512 gene
- * words (config 3: 4 096 of each 16 384-drone tile; the streaming part then takes waves_per_block = 8). */
-int64_t ld_fly_rollout_cached_drones_f32(const ld_mlp_spec *spec, int64_t n, int32_t timesteps);
+/* Accounting: gene words per drone (16 bytes each) that a launch of ld_fly_steps_f32(..., n_steps, waves_per_block)
+ * keeps in LDS for the whole launch and gene words per drone it streams from memory EVERY timestep (0 and
+ * ld_mlp_words_per_drone when the launch keeps nothing; a word that straddles two wavefronts' rows is loaded by
+ * both, so the two can add up to a little more than that). */
+int ld_fly_steps_kept_words_f32(const ld_mlp_spec *spec, int32_t waves_per_block, int32_t n_steps,
+                                int64_t *kept_words, int64_t *streamed_words);
 
 /* The wavefronts per genome block ld_fly_steps_f32 takes for waves_per_block = 0 on a launch of n drones and
  * n_steps timesteps (1 for specs without an unrolled specialisation), or a negative ld_status. */

@@ -26,11 +26,11 @@ EXPORTS = (
     "ld_fly_finalize_f32", "ld_fly_finalize_f64", "ld_fly_rollout_f32", "ld_fly_rollout_f64",
     "ld_ga_select", "ld_ga_breed_f32", "ld_ga_breed_f64", "ld_pid_episode_f32", "ld_pid_episode_f64",
     "ld_fly_rollout_resident_f32", "ld_debug_force_generic", "ld_accelerations_f32", "ld_accelerations_f64",
-    "ld_fly_steps_f32", "ld_fly_rollout_steps_f32", "ld_fly_rollout_geometry_f32", "ld_fly_rollout_cached_drones_f32", "ld_fly_steps_resident_f32",
+    "ld_fly_steps_f32", "ld_fly_rollout_steps_f32", "ld_fly_rollout_geometry_f32", "ld_fly_steps_kept_words_f32", "ld_accelerations_frames_f32", "ld_accelerations_frames_f64", "ld_fly_steps_resident_f32",
     "ld_fly_rollout_resident_f64", "ld_register_specialisation_f32", "ld_has_specialisation_f32",
     "ld_has_resident_f32", "ld_has_resident_f64", "ld_fly_steps_auto_waves_f32", "ld_debug_lds_keep",
 )
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -108,8 +108,9 @@ def _declare(h: C.CDLL) -> None:
     h.ld_has_resident_f32.argtypes = [spec]
     h.ld_has_resident_f64.argtypes = [spec]
     h.ld_fly_steps_auto_waves_f32.argtypes = [spec, i64, i32]
-    h.ld_fly_rollout_cached_drones_f32.argtypes = [spec, i64, i32]
-    h.ld_fly_rollout_cached_drones_f32.restype = C.c_int64
+    h.ld_fly_steps_kept_words_f32.argtypes = [spec, i32, i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    h.ld_accelerations_frames_f32.argtypes = [sim, vp, vp, vp, vp, vp, i32, i64, vp]
+    h.ld_accelerations_frames_f64.argtypes = [sim, vp, vp, vp, vp, vp, i32, i64, vp]
     h.ld_fly_steps_resident_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, i64, i32, vp, vp]
     pi32 = C.POINTER(C.c_int32)
     h.ld_fly_rollout_geometry_f32.argtypes = [spec, i64, i32, pi32, pi32, pi32, C.POINTER(C.c_int64)]
@@ -121,7 +122,7 @@ def _declare(h: C.CDLL) -> None:
         getattr(h, f"ld_pid_episode_{sfx}").argtypes = [sim, vp, vp, i32, C.c_double, i32, i32, vp, vp, vp, vp, vp, i64, vp]
     for name in EXPORTS:
         if name not in ("ld_strerror", "ld_last_hip_error", "ld_mlp_param_count", "ld_mlp_words_per_drone",
-                        "ld_genome_words", "ld_fly_rollout_cached_drones_f32"):
+                        "ld_genome_words"):
             getattr(h, name).restype = C.c_int
 
 
@@ -154,6 +155,14 @@ def check(status: int, what: str) -> None:
         h = lib()
         detail = h.ld_strerror(status).decode()
         hip = h.ld_last_hip_error().decode()
+        # a run-time specialisation is a shared object of its own (loaded RTLD_LOCAL) with its own copy of the
+        # per-thread error text: a launch failure inside one of its kernels is reported there
+        for key, so in _specialised.items():
+            if hasattr(so, "ld_spec_last_hip_error"):
+                so.ld_spec_last_hip_error.restype = C.c_char_p
+                text = so.ld_spec_last_hip_error().decode()
+                if text:
+                    hip += f"{'; ' if hip else ''}[specialisation {key}] {text}"
         raise LdError(what, status, detail + (f"; {hip}" if hip else ""))
 
 

@@ -42,6 +42,9 @@ std::atomic<int> g_lds_keep{-1};              // ld_debug_lds_keep: -1 = the lib
 #ifndef LD_KEEP_MIN_STEPS
 #define LD_KEEP_MIN_STEPS 8
 #endif
+#ifndef LD_KEEP_KIB
+#define LD_KEEP_KIB 136                        // = LD_SPLIT_KEEP_KIB of ld_split.inc
+#endif
 int keep_bit(int32_t n_steps)
 {
     const int mode = g_lds_keep.load(std::memory_order_relaxed);
@@ -93,6 +96,11 @@ int check_episode(const ld_episode_params* ep, const double* coins, const double
     if (ep->n_walls > 0 && !walls) return LD_ERR_NULL;
     return LD_OK;
 }
+
+// waves_per_block values of the ABI: 0 = the library's choice; 1, 2, 4, 8 = one workgroup of that many wavefronts per
+// 64-drone genome block; 16, 32 = two, four workgroups of 8 (of 4 for the nets wider than 512 gene words); 11 = workgroups
+// of 8 wavefronts that fly 48 consecutive drones each (launches that keep genes in LDS only).
+bool valid_waves(int32_t w) { return w == 0 || w == 1 || w == 2 || w == 4 || w == 8 || w == 16 || w == 32 || w == 11; }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -171,11 +179,52 @@ bool keeps_genes(const ld_mlp_spec* spec, int32_t n_steps)
     return keep_bit(n_steps) != 0 && ld_mlp_words_per_drone(spec) <= 512 && even_split(spec, 8);
 }
 
+// What KeepPlan<8, ...> (ld_split.hpp) works out at compile time, at run time, for the accounting entry point
+// ld_fly_steps_kept_words_f32: gene words per drone a launch keeps in LDS and gene words per drone it streams every
+// timestep, for workgroups of 8 wavefronts flying `lanes` drones each.  (A word that straddles two wavefronts' rows is
+// loaded by both: the two numbers add up to a little more than ld_mlp_words_per_drone.)
+void keep_plan(const ld_mlp_spec& spec, int lanes, int64_t* kept, int64_t* streamed)
+{
+    constexpr int L = 8;
+    int dims[LD_MAX_HIDDEN_LAYERS + 2];
+    dims[0] = LD_N_INPUTS;
+    for (int i = 0; i < spec.n_hidden; ++i) dims[i + 1] = spec.hidden[i];
+    dims[spec.n_hidden + 1] = LD_N_OUTPUTS;
+    const int layers = spec.n_hidden + 1;
+    int64_t len[L], total = 0;
+    for (int k = 0; k < L; ++k) {
+        len[k] = 0;
+        int64_t offset = 0;
+        for (int l = 0; l < layers; ++l) {
+            const int64_t row0 = (int64_t)k * dims[l + 1] / L, row1 = (int64_t)(k + 1) * dims[l + 1] / L, stride = dims[l] + 1;
+            if (row1 > row0) len[k] += (offset + row1 * stride + 3) / 4 - (offset + row0 * stride) / 4;
+            offset += (int64_t)dims[l + 1] * stride;
+        }
+        total += len[k];
+    }
+    const int64_t keep_words = (int64_t)LD_KEEP_KIB * 1024 / (lanes * 16);
+    *kept = 0;
+    for (int k = 0; k < L; ++k) {
+        const int64_t want = len[k] * keep_words / total;
+        *kept += want < len[k] ? want : len[k];
+    }
+    *streamed = total - *kept;
+}
+
 int auto_waves_per_block(const ld_mlp_spec* spec, int64_t n, int32_t n_steps)
 {
     const int64_t blocks = (n + 63) / 64;
     if (keeps_genes(spec, n_steps)) {
-        int groups = 1;
+        // A workgroup of 8 wavefronts keeps 136 KiB of its drones' genes in LDS and has its CU to itself, so 256 workgroups
+        // are resident at a time and what they STREAM per timestep should fit the L2s (32 MB): then the stream never
+        // reaches the Infinity Cache fabric and a timestep takes what its dependent chain takes (3.2-3.8 us for 32-32).
+        // Workgroups of 64 / 32 / 16 drones keep 136 / 272 / 544 gene words per drone and stream 16 (W - kept) bytes for
+        // each of 16 384 / 8 192 / 4 096 resident drones: within ~24 MB for W <= 227 / 455 / any.  Measured, 32-32 (W = 425),
+        // us per timestep at 8 / 16 / 32 wavefronts per block: 65 536 drones in one launch 40.8 / 29.4 / 52.2, 8 192: 6.8 /
+        // 3.8 / 6.6, 4 096: 5.9 / 3.6 / 3.2 (profiles/r03_lds_keep.json).  Small launches then take the workgroups per
+        // block that give every CU one.
+        const int64_t words = ld_mlp_words_per_drone(spec);
+        int groups = words <= 227 ? 1 : (words <= 455 ? 2 : 4);
         while (groups < 4 && blocks * groups < 256) groups *= 2;
         return 8 * groups;
     }
@@ -226,21 +275,6 @@ int dispatch_split_f32(const ld_sim_params* sim, const ld_episode_params* ep, co
 #undef X
     if (const Specialisation* s = find_specialisation(*spec))
         return s->fly_steps(sim, ep, coins, walls, genomes, fstate, istate, n, begin, end, n_steps, waves, stream);
-    return LD_ERR_SPEC;
-}
-
-// The same drones by two workgroups of 8 wavefronts per block with cacheable gene loads (shipped specs of up to 512
-// gene words; LD_ERR_SPEC / LD_ERR_SIZE otherwise).
-int dispatch_split_cached_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec, const double* coins,
-                              const double* walls, const float* genomes, float* fstate, int32_t* istate, int64_t n, int64_t begin,
-                              int64_t end, int32_t n_steps, hipStream_t stream)
-{
-#define X(TAG, ...)                                                                                          \
-    if (spec_is<__VA_ARGS__>(*spec))                                                                         \
-        return ld_u_split_cached_f32_##TAG(sim, ep, coins, walls, genomes, fstate, istate, n, begin, end, n_steps, stream, \
-                                           keep_bit(n_steps));
-    LD_FOR_EACH_UNROLLED(X)
-#undef X
     return LD_ERR_SPEC;
 }
 
@@ -326,6 +360,10 @@ int auto_steps_per_launch() { return LD_STEPS_PER_LAUNCH; }
 // tile must still fill the chip, so only nets small enough for >= 16 384 drones per tile are tiled.
 int64_t auto_tile_drones(const ld_mlp_spec* spec, int64_t n, int32_t steps_per_launch)
 {
+    // launches that keep genes in LDS: the working set is what the RESIDENT workgroups stream (each runs all its
+    // timesteps before the next workgroup takes its CU), whatever the launch covers: 65 536 x 32-32 in one launch 29.4 us
+    // per timestep, as eight tiles of 8 192 8 x 3.75
+    if (keeps_genes(spec, steps_per_launch)) return n;
     if (steps_per_launch < 4) return n;      // one-timestep launches of 16 384 drones are latency-bound (18.4 vs 4 x 17 us whole)
     const int64_t bytes_per_drone = 4 * ld_mlp_param_count(spec);
     if (n * bytes_per_drone <= (int64_t)LD_TILE_WHOLE_BELOW) return n;            // fits as it is
@@ -335,55 +373,13 @@ int64_t auto_tile_drones(const ld_mlp_spec* spec, int64_t n, int32_t steps_per_l
     return tile < n ? tile : n;
 }
 
-// ---- part of a tile kept in the L2s ---------------------------------------------------------------------------------
-// A tile's genes are re-streamed from the Infinity Cache every timestep, and the fabric between it and the L2s is what
-// bounds the tile (8 TB/s).  The L2s themselves (8 x 4 MB) could hold a quarter of a 32-32 tile, but the non-temporal
-// stream of all of it leaves nothing in them.  So the first `cached` drones of a tile are flown by a SECOND launch, on
-// a side stream, whose gene loads are cacheable (two workgroups of 8 wavefronts per block), concurrently with the
-// rest of the tile on the caller's stream (one workgroup of 8, non-temporal): the L2s keep a good part of the first
-// group's genes from timestep to timestep and that share of the re-streams never reaches the fabric.  16 384 drones
-// of 32-32, 64 timesteps: 813 -> 745 us (scripts/exp_l2_partition.py, profiles/r02_l2_partition.json; both parts
-// non-temporal: 845-865 us, everything cacheable: 1 020 us).  Both launches run the same per-lane instruction
-// streams as any other geometry: bit-identical results.
-#ifndef LD_L2_KEEP_BYTES
-#define LD_L2_KEEP_BYTES (28u << 20)               // of the 32 MB of L2: 4 096 drones of 32-32
-#endif
-int64_t auto_cached_drones(const ld_mlp_spec* spec, int64_t tile, int32_t steps_per_launch)
-{
-    if (steps_per_launch < 4 || tile < (1 << 14) || ld_mlp_words_per_drone(spec) > 512 || !even_split(spec, 8)) return 0;
-    if (find_specialisation(*spec)) return 0;        // run-time specialisations do not carry the cacheable variant
-    const int64_t keep = ((int64_t)LD_L2_KEEP_BYTES / (4 * ld_mlp_param_count(spec))) / 64 * 64;
-    return keep * 3 <= tile ? keep : 0;              // a minor part of the tile only (measured: 32-32 +7 %; with half the tile cached 16-16 -29 %, 15-16-4 -42 %, 15-64-4 +5 %)
-}
-
-struct SideStream {                                   // one per host thread and device, made at first use
-    int device = -1;
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    bool ready()
-    {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return false;
-        if (stream && dev == device) return true;
-        if (stream) { (void)hipEventDestroy(fork); (void)hipEventDestroy(join); (void)hipStreamDestroy(stream); stream = nullptr; }
-        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { stream = nullptr; return false; }
-        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) {
-            (void)hipStreamDestroy(stream); stream = nullptr; return false;
-        }
-        device = dev;
-        return true;
-    }
-};
-thread_local SideStream t_side;
-
 int rollout_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec, const double* coins,
                       const double* walls, const float* genomes, float* fstate, int32_t* istate,
                       ld_fitness_record* records, int64_t n, int32_t timesteps, int32_t steps_per_launch, int32_t waves,
                       int64_t tile_drones, void* stream)
 {
     if (timesteps < 0 || steps_per_launch < 0 || tile_drones < 0 || (tile_drones % 64) != 0) return LD_ERR_SIZE;
-    if (waves != 0 && waves != 1 && waves != 2 && waves != 4 && waves != 8 && waves != 16 && waves != 32) return LD_ERR_SIZE;
+    if (!valid_waves(waves)) return LD_ERR_SIZE;
     int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
     if (rc || n == 0) return rc;
     if (steps_per_launch == 0) steps_per_launch = auto_steps_per_launch();
@@ -397,33 +393,14 @@ int rollout_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, con
         }
         return finalize_impl<float>(ep, coins, fstate, istate, records, nullptr, n, stream);
     }
-    const bool own_geometry = waves == 0 && tile_drones == 0;             // the library's choice: it may keep part of a tile in L2
     if (tile_drones == 0) tile_drones = auto_tile_drones(spec, n, steps_per_launch);
-    hipStream_t main = static_cast<hipStream_t>(stream);
     for (int64_t begin = 0; begin < n; begin += tile_drones) {              // a tile's whole episode, then the next tile
         const int64_t end = begin + tile_drones < n ? begin + tile_drones : n;
-        int64_t cached = own_geometry ? auto_cached_drones(spec, end - begin, steps_per_launch) : 0;
-        if (cached && !t_side.ready()) cached = 0;
-        if (cached) {                                                      // fork: the side stream joins the caller's stream here
-            hipError_t e = hipEventRecord(t_side.fork, main);
-            if (e == hipSuccess) e = hipStreamWaitEvent(t_side.stream, t_side.fork, 0);
-            if (e != hipSuccess) return hip_fail(e, "fork of the side stream");
-        }
         for (int32_t t = 0; t < timesteps; t += steps_per_launch) {
             const int32_t k = timesteps - t < steps_per_launch ? timesteps - t : steps_per_launch;
-            if (cached) {
-                rc = dispatch_split_cached_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, begin, begin + cached, k,
-                                               t_side.stream);
-                if (rc) return rc;
-            }
-            rc = dispatch_split_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, begin + cached, end, k,
-                                    cached ? 8 : waves, main);
+            rc = dispatch_split_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, n, begin, end, k, waves,
+                                    static_cast<hipStream_t>(stream));
             if (rc) return rc;
-        }
-        if (cached) {                                                      // join: the caller's stream waits for the side stream
-            hipError_t e = hipEventRecord(t_side.join, t_side.stream);
-            if (e == hipSuccess) e = hipStreamWaitEvent(main, t_side.join, 0);
-            if (e != hipSuccess) return hip_fail(e, "join of the side stream");
         }
     }
     return finalize_impl<float>(ep, coins, fstate, istate, records, nullptr, n, stream);
@@ -477,6 +454,20 @@ int accelerations_impl(const ld_sim_params* sim, const Real* angle, const Real* 
     hipLaunchKernelGGL((ld::accelerations_kernel<Real, Faithful>), dim3(blocks_for(n, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), ld::make_sim<Real>(*sim), angle, thrust, lin_acc, rot_acc, n);
     return check_launch("accelerations_kernel");
+}
+
+template <typename Real, bool Faithful>
+int accelerations_frames_impl(const ld_sim_params* sim, const Real* angle, const Real* thrust, Real* lin_acc, Real* rot_acc,
+                              Real* rot_matrix, int32_t lab_frame, int64_t n, void* stream)
+{
+    if (!sim) return LD_ERR_NULL;
+    if (n < 0) return LD_ERR_SIZE;
+    if (n == 0) return LD_OK;
+    if (!angle || !thrust || !lin_acc || !rot_acc) return LD_ERR_NULL;
+    hipLaunchKernelGGL((ld::accelerations_frames_kernel<Real, Faithful>), dim3(blocks_for(n, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), ld::make_sim<Real>(*sim), angle, thrust, lin_acc, rot_acc, rot_matrix,
+                       lab_frame, n);
+    return check_launch("accelerations_frames_kernel");
 }
 
 template <typename Real, bool Fma>
@@ -710,14 +701,19 @@ int ld_accelerations_f64(const ld_sim_params* sim, const double* angle, const do
                          double* rot_acc, int64_t n, void* stream)
 { return accelerations_impl<double, true>(sim, angle, thrust, lin_acc, rot_acc, n, stream); }
 
+int ld_accelerations_frames_f32(const ld_sim_params* sim, const float* angle, const float* thrust, float* lin_acc, float* rot_acc,
+                                float* rot_matrix, int32_t lab_frame, int64_t n, void* stream)
+{ return accelerations_frames_impl<float, false>(sim, angle, thrust, lin_acc, rot_acc, rot_matrix, lab_frame, n, stream); }
+int ld_accelerations_frames_f64(const ld_sim_params* sim, const double* angle, const double* thrust, double* lin_acc,
+                                double* rot_acc, double* rot_matrix, int32_t lab_frame, int64_t n, void* stream)
+{ return accelerations_frames_impl<double, true>(sim, angle, thrust, lin_acc, rot_acc, rot_matrix, lab_frame, n, stream); }
+
 int ld_fly_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec, const double* coins,
                      const double* walls, const float* genomes, float* fstate, int32_t* istate, int64_t n, int32_t n_steps,
                      int32_t waves_per_block, void* stream)
 {
     if (n_steps < 0) return LD_ERR_SIZE;
-    if (waves_per_block != 0 && waves_per_block != 1 && waves_per_block != 2 && waves_per_block != 4 && waves_per_block != 8 &&
-        waves_per_block != 16 && waves_per_block != 32)
-        return LD_ERR_SIZE;
+    if (!valid_waves(waves_per_block)) return LD_ERR_SIZE;
     const int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
     if (rc || n == 0 || n_steps == 0) return rc;
     if (!has_unrolled(*spec)) {                     // run-time layer spec: one wavefront per block is the only geometry
@@ -740,17 +736,23 @@ int ld_fly_rollout_geometry_f32(const ld_mlp_spec* spec, int64_t n, int32_t time
     *steps_per_launch = auto_steps_per_launch();
     *tile_drones = split && n > 0 ? auto_tile_drones(spec, n, *steps_per_launch) : n;
     *waves_per_block = split ? auto_waves_per_block(spec, *tile_drones, *steps_per_launch) : 1;
-    if (split && auto_cached_drones(spec, *tile_drones, *steps_per_launch) > 0) *waves_per_block = 8;   // the streaming part's
     const int64_t tiles = *tile_drones > 0 ? (n + *tile_drones - 1) / *tile_drones : 1;
     *n_launches = (int32_t)(tiles * ((timesteps + *steps_per_launch - 1) / *steps_per_launch));
     return LD_OK;
 }
 
-int64_t ld_fly_rollout_cached_drones_f32(const ld_mlp_spec* spec, int64_t n, int32_t timesteps)
+int ld_fly_steps_kept_words_f32(const ld_mlp_spec* spec, int32_t waves_per_block, int32_t n_steps, int64_t* kept_words,
+                                int64_t* streamed_words)
 {
-    if (check_spec(spec) != LD_OK || n <= 0 || timesteps < 0 || !has_unrolled(*spec)) return 0;
-    const int32_t k = auto_steps_per_launch();
-    return auto_cached_drones(spec, auto_tile_drones(spec, n, k), k);
+    const int rc = check_spec(spec);
+    if (rc) return rc;
+    if (!valid_waves(waves_per_block) || n_steps < 0) return LD_ERR_SIZE;
+    if (!kept_words || !streamed_words) return LD_ERR_NULL;
+    *kept_words = 0;
+    *streamed_words = ld_mlp_words_per_drone(spec);
+    const int lanes = waves_per_block == 8 ? 64 : waves_per_block == 11 ? 48 : waves_per_block == 16 ? 32 : waves_per_block == 32 ? 16 : 0;
+    if (lanes && has_unrolled(*spec) && ld_mlp_words_per_drone(spec) <= 512 && keep_bit(n_steps)) keep_plan(*spec, lanes, kept_words, streamed_words);
+    return LD_OK;
 }
 
 int ld_fly_steps_auto_waves_f32(const ld_mlp_spec* spec, int64_t n, int32_t n_steps)

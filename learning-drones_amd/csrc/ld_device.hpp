@@ -108,6 +108,46 @@ __device__ __forceinline__ void accel_closed_sc(const Sim& p, const Real sc[6], 
     rot[2] = (sr * b1 + cr * b2) * inv_cp;
 }
 
+// The body-frame pair of physical_model.py:114-115 (what calculate_accelerations returns with
+// lin_acc_drone_2_lab=False) and the rotation matrix it leaves in self.Rot (:90), closed form: with B = Rz Ry Rx and
+// Rot = B^T,  forces = [0, 0, sum(T)] + Rot [0, 0, -G] + Rot (wind c_w),  lin = forces / m,  rot = (moments + M_p) / I.
+// rot_out: row-major Rot, or nullptr.
+template <typename Real, typename Sim>
+__device__ __forceinline__ void accel_closed_body(const Sim& p, const Real ang[3], const Real u[4], Real lin[3], Real rot[3],
+                                                  Real* rot_out)
+{
+    Real sr, cr, sp, cp, sy, cy;
+    Math<Real>::sincos(ang[0], &sr, &cr);
+    Math<Real>::sincos(ang[1], &sp, &cp);
+    Math<Real>::sincos(ang[2], &sy, &cy);
+    const Real B[3][3] = {{cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr},
+                          {sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr},
+                          {-sp, cp * sr, cp * cr}};
+    const Real cf = (Real)p.coef_force, cm = (Real)p.coef_moment, r = (Real)p.radius_motor;
+    const Real inv_m = (Real)1 / (Real)p.mass_total;
+    const Real T0 = u[0] * cf, T1 = u[1] * cf, T2 = u[2] * cf, T3 = u[3] * cf;
+    const Real R0 = u[0] * cm, R1 = u[1] * cm, R2 = u[2] * cm, R3 = u[3] * cm;
+    const Real sumT = ((T0 + T1) + T2) + T3;
+    const Real cw = (Real)p.coef_wind;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {                              // Rot[i][k] = B[k][i]
+        const Real wind = (B[0][i] * ((Real)p.wind[0] * cw) + B[1][i] * ((Real)p.wind[1] * cw)) + B[2][i] * ((Real)p.wind[2] * cw);
+        lin[i] = ((i == 2 ? sumT : (Real)0) - B[2][i] * (Real)p.gravity_force + wind) * inv_m;
+    }
+    const Real L = r * (((T0 + T3) - T1) - T2);
+    const Real M = r * (((T2 + T3) - T0) - T1);
+    const Real N = ((Real)1.4142135623730951 * r) * (((R1 + R3) - R0) - R2);
+    rot[0] = (L + (Real)p.moments_payload[0]) * (Real)p.inv_inertia[0];
+    rot[1] = (M + (Real)p.moments_payload[1]) * (Real)p.inv_inertia[1];
+    rot[2] = (N + (Real)p.moments_payload[2]) * (Real)p.inv_inertia[2];
+    if (rot_out) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) rot_out[3 * i + k] = B[k][i];
+    }
+}
+
 template <typename Real, typename Sim>
 __device__ __forceinline__ void accel_closed(const Sim& p, const Real ang[3], const Real u[4],
                                              Real lin[3], Real rot[3])
@@ -135,9 +175,10 @@ __device__ __forceinline__ double dot3_gemv_c(double a0, double b0, double a1, d
     return ::fma(a2, b2, ::fma(a0, b0, a1 * b1));
 }
 
+// lab = the reference's lin_acc_drone_2_lab; rot_out (may be nullptr) = self.Rot, row-major (physical_model.py:90).
 template <typename Sim>
-__device__ __forceinline__ void accel_faithful(const Sim& p, const double ang[3], const double u[4],
-                                               double lin[3], double rot[3])
+__device__ __forceinline__ void accel_faithful_frames(const Sim& p, const double ang[3], const double u[4],
+                                                      double lin[3], double rot[3], double* rot_out, bool lab)
 {
     const double roll = ang[0], pitch = ang[1], yaw = ang[2];
     const double cr = ::cos(roll), sr = ::sin(roll), cp = ::cos(pitch), sp = ::sin(pitch);
@@ -180,6 +221,17 @@ __device__ __forceinline__ void accel_faithful(const Sim& p, const double ang[3]
     const float m32 = (float)p.mass_total;
     const float a32[3] = {F[0] / m32, F[1] / m32, F[2] / m32};             // (4) :114 stays float32
     const double b[3] = {mom[0] * p.inv_inertia[0], mom[1] * p.inv_inertia[1], mom[2] * p.inv_inertia[2]};
+    if (rot_out) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) rot_out[3 * i + k] = B[k][i];
+    }
+    if (!lab) {                                                           // :117 not taken
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { lin[i] = (double)a32[i]; rot[i] = b[i]; }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i)                                           // :118  Rot^T . lin_acc
         lin[i] = dot3_gemv_c(B[i][0], (double)a32[0], B[i][1], (double)a32[1], B[i][2], (double)a32[2]);
@@ -190,6 +242,13 @@ __device__ __forceinline__ void accel_faithful(const Sim& p, const double ang[3]
 #pragma unroll
     for (int i = 0; i < 3; ++i)                                           // :119-120
         rot[i] = dot3_gemv_c((double)Tr[i][0], b[0], (double)Tr[i][1], b[1], (double)Tr[i][2], b[2]);
+}
+
+template <typename Sim>
+__device__ __forceinline__ void accel_faithful(const Sim& p, const double ang[3], const double u[4],
+                                               double lin[3], double rot[3])
+{
+    accel_faithful_frames(p, ang, u, lin, rot, nullptr, true);
 }
 
 template <typename Real, bool Faithful, typename Sim>

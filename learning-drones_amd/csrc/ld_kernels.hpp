@@ -251,6 +251,40 @@ accelerations_kernel(const SimT<Real> sim, const Real* __restrict__ angle, const
     for (int k = 0; k < 3; ++k) { lin_acc[(int64_t)k * n + i] = lin[k]; rot_acc[(int64_t)k * n + i] = rot[k]; }
 }
 
+// ... with the reference's lin_acc_drone_2_lab argument and its self.Rot side effect (physical_model.py:90, :117-120):
+// lab_frame == 0 returns the body-frame pair; rot_matrix [9][n] (row-major entries of Rot) or nullptr.
+template <typename Real, bool Faithful>
+__global__ void __launch_bounds__(256)
+accelerations_frames_kernel(const SimT<Real> sim, const Real* __restrict__ angle, const Real* __restrict__ thrust,
+                            Real* __restrict__ lin_acc, Real* __restrict__ rot_acc, Real* __restrict__ rot_matrix,
+                            const int32_t lab_frame, const int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Real a[3], u[4], lin[3], rot[3], mat[9];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a[k] = angle[(int64_t)k * n + i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = thrust[(int64_t)k * n + i];
+    if constexpr (Faithful) {
+        accel_faithful_frames(sim, a, u, lin, rot, mat, lab_frame != 0);
+    } else {
+        Real body_lin[3], body_rot[3];
+        accel_closed_body<Real>(sim, a, u, body_lin, body_rot, mat);
+        if (lab_frame) accelerations<Real, false>(sim, a, u, lin, rot);      // the arithmetic of ld_accelerations_f32 itself
+        else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { lin[k] = body_lin[k]; rot[k] = body_rot[k]; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { lin_acc[(int64_t)k * n + i] = lin[k]; rot_acc[(int64_t)k * n + i] = rot[k]; }
+    if (rot_matrix) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) rot_matrix[(int64_t)k * n + i] = mat[k];
+    }
+}
+
 // Tail of fly() (flight/__init__.py:83-87,97-99).
 template <typename Real>
 __global__ void __launch_bounds__(256)

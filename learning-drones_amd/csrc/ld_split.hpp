@@ -23,6 +23,11 @@
 
 #include "ld_kernels.hpp"
 
+// kept gene words in flight from LDS per lane (4: the all-in-LDS launches 3.32 -> 3.15 us per timestep against 2)
+#ifndef LD_SPLIT_KEEP_DEPTH
+#define LD_SPLIT_KEEP_DEPTH 4
+#endif
+
 namespace ld {
 
 // Which rows, which gene words and which positions of its private word stream wavefront k has.
@@ -98,7 +103,7 @@ template <int L, int KeepWords, int... H> struct KeepPlan {
         for (int j = 0; j < k; ++j) b += count(j);
         return b;
     }
-    static constexpr int rows = base(L) + 2;                     // (+2: the top-of-step reads of a wavefront with fewer than two kept words)
+    static constexpr int rows = base(L) + LD_SPLIT_KEEP_DEPTH;  // (the top-of-step reads of a wavefront with fewer kept words than it keeps in flight)
     static constexpr int kept_before(int k, int s) { return (int)((long long)s * count(k) / Plan::stream_len(k)); }
     static constexpr bool kept(int k, int s) { return count(k) > 0 && kept_before(k, s + 1) != kept_before(k, s); }
     static constexpr int streamed_before(int k, int s) { return s - kept_before(k, s); }
@@ -163,6 +168,22 @@ __device__ __forceinline__ void split_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Diagnostic build only (scripts/micro/split_stamps.hip defines LD_DIAG_STAMPS): where a timestep's cycles go, per
+// wavefront of the workgroup.  s_memtime stamps at the top of the step, behind the rigid-body step and behind every
+// layer's barrier, summed per segment into ld_diag_cycles[wave][segment] (the shipped kernels contain none of this).
+#ifdef LD_DIAG_STAMPS
+extern __device__ unsigned long long ld_diag_cycles[8][8];
+#define LD_STAMP(var)                                                                  \
+    unsigned long long var;                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");        \
+    __builtin_amdgcn_sched_barrier(0);
+#define LD_STAMP_ADD(seg, a, b) diag_sum[seg] += (b) - (a);
+#else
+#define LD_STAMP(var)
+#define LD_STAMP_ADD(seg, a, b)
+#endif
+
 // Ring depth caps: a wavefront has 512 registers at L <= 4 (one wavefront per SIMD), 256 at L = 8.
 #ifndef LD_SPLIT_DEPTH_CAP
 #define LD_SPLIT_DEPTH_CAP 32
@@ -173,15 +194,22 @@ __device__ __forceinline__ void split_barrier()
 #ifndef LD_SPLIT_HEAD_L8
 #define LD_SPLIT_HEAD_L8 8
 #endif
+// ... and of the kernels that keep genes in LDS: 8 words.  Measured (scripts/exp_lds_keep4.py, 32-32, us per timestep at a
+// ring of 16 / 12 / 8 / 4 words): 8 192 drones in workgroups of 32: 5.49 / 5.45 / 3.82 / 4.53; 65 536 in one launch: 43.3 /
+// 42.9 / 29.9 / 35.8; workgroups of 64 and of 48 drones do not care (9.3 and 6.0-6.1 throughout).  With 64 % of the genes in
+// LDS the streamed rest of the resident workgroups' genes (20 MB chip-wide) is about what the L2s hold, and the shallower
+// ring leaves it there.
+#ifndef LD_SPLIT_DEPTH_CAP_KEEP
+#define LD_SPLIT_DEPTH_CAP_KEEP 8
+#endif
 
 // S > 1: a 64-drone genome block is served by S workgroups of L wavefronts, each flying 64 / S of its drones on
 // the first 64 / S lanes of its wavefronts (the other lanes leave at once).  A shard of 8 192 drones is 128
 // genome blocks: one workgroup per block occupies 128 of the 256 CUs, and each of those pulls its block's genes
 // at the most one CU can draw from L2 / Infinity Cache (~50 GB/s); two workgroups per block use every CU.
-// Streamed = the genes are loaded with the non-temporal hint (the default); false = cacheable loads, for the part of a
-// tile that ld_fly_rollout_f32 asks the L2s to keep (ld_abi.hip, rollout_steps_f32).
+// The genes are loaded with the non-temporal hint (ld_device.hpp, LD_GENE_NT).
 // KeepKiB > 0: that many KiB of the workgroup's LDS hold gene words for the whole launch (KeepPlan above).
-template <typename Real, bool Faithful, int L, int S, bool Streamed, int KeepKiB, int... H>
+template <typename Real, bool Faithful, int L, int S, int KeepKiB, int... H>
 __global__ void __launch_bounds__(64 * L)
 fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restrict__ coins,
                  const double* __restrict__ walls, const GeneWord<Real>* __restrict__ genomes,
@@ -198,15 +226,17 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
     // words in flight per lane (ld_nets.hpp: 32 for the small nets, 16 for the 64-wide ones), within the
     // registers a wavefront has when 2 of them share a SIMD (L = 8: 256)
     constexpr int kWantBase = sizeof(Real) == 4 ? (Shape::W <= 512 ? LD_DEPTH_F32_SMALL_NET : LD_DEPTH_F32) : LD_DEPTH_F64;
-    constexpr int kCap = L >= 8 ? LD_SPLIT_DEPTH_CAP_L8 : LD_SPLIT_DEPTH_CAP;
+    constexpr int kCap = KeepKiB > 0 ? LD_SPLIT_DEPTH_CAP_KEEP : (L >= 8 ? LD_SPLIT_DEPTH_CAP_L8 : LD_SPLIT_DEPTH_CAP);
     constexpr int kWant = kWantBase < kCap ? kWantBase : kCap;
-    constexpr int kLanes = 64 / S;                            // drones (= active lanes) per wavefront
+    // drones (= active lanes) per wavefront: 64 / S, and 48 for S = 3 (workgroups of 48 consecutive drones, which
+    // straddle the 64-drone genome blocks: a gene word is then 768 bytes in two pieces of whole 128-byte lines)
+    constexpr int kLanes = S == 3 ? 48 : 64 / S;
     constexpr int kKeepWords = KeepKiB * 1024 / (kLanes * (int)sizeof(GeneWord<Real>));
     using Keep = KeepPlan<L, kKeepWords, H...>;
     constexpr bool kKeeps = kKeepWords > 0;
     constexpr int kStreamMax = Keep::max_streamed_len() > 0 ? Keep::max_streamed_len() : 1;
     constexpr int D = kWant < kStreamMax ? kWant : kStreamMax;
-    constexpr int KD = 2;                                     // kept words in flight from LDS per lane
+    constexpr int KD = LD_SPLIT_KEEP_DEPTH;                   // kept words in flight from LDS per lane
 
     __shared__ Tables<Real> tab;
     __shared__ Real xch[Plan::xch_rows][64];
@@ -215,7 +245,7 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
     const int lane = threadIdx.x & 63;
     if (S > 1 && lane >= kLanes) return;
     const int wave = L == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t gid = begin + (int64_t)(blockIdx.x / S) * 64 + (blockIdx.x % S) * kLanes + lane;
+    const int64_t gid = begin + (int64_t)blockIdx.x * kLanes + lane;
     const bool valid = gid < end;
     const int64_t i = valid ? gid : end - 1;                  // tail lanes read the last drone, store nothing
 
@@ -243,7 +273,7 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
             constexpr int N = Keep::streamed_len(K);
             static_for<A, (B < N ? B : N)>([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value;
-                ring[q] = load_word<Real, Streamed>(genomes, lane_offset, Plan::word_at(K, Keep::pos_of_streamed(K, q)));
+                ring[q] = load_word<Real>(genomes, lane_offset, Plan::word_at(K, Keep::pos_of_streamed(K, q)));
             });
         });
     };
@@ -260,7 +290,7 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
                 constexpr int c0 = decltype(cc)::value * D, c1 = c0 + D < R ? c0 + D : R;
                 static_for<c0, c1>([&](auto jc) __attribute__((always_inline)) {
                     constexpr int j = decltype(jc)::value;
-                    ring[j - c0] = load_word<Real, true>(genomes, lane_offset, Plan::word_at(K, Keep::pos_of_kept(K, j)));
+                    ring[j - c0] = load_word<Real>(genomes, lane_offset, Plan::word_at(K, Keep::pos_of_kept(K, j)));
                 });
                 static_for<c0, c1>([&](auto jc) __attribute__((always_inline)) {
                     constexpr int j = decltype(jc)::value;
@@ -274,8 +304,12 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
     // register allocator keeps two copies of the ring.
     bool dead0 = false, dead = false;
     int32_t flight_time = 0;
+#ifdef LD_DIAG_STAMPS
+    unsigned long long diag_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int32_t t = 0; t < n_steps; ++t) {
         if (t > 0 && __all(dead)) break;                      // every wavefront of the block sees the same 64 drones
+        LD_STAMP(st_top)
         prefetch(std::integral_constant<int, 0>{});
         if constexpr (kKeeps) {
 #pragma unroll
@@ -317,7 +351,12 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
         dead = was_dead || crashed;
         current_coin<Real>(ep, tab.coins, ncoll, c);
 
+        LD_STAMP(st_phys)
+        LD_STAMP_ADD(0, st_top, st_phys)
         if constexpr (kHead < D) prefetch(std::integral_constant<int, 1>{});
+#ifdef LD_DIAG_STAMPS
+        unsigned long long st_prev = st_phys;
+#endif
 
         // ---- controller on the post-step state (evolve/brain.py:41-54); frozen lanes compute on their
         // frozen state and discard the result
@@ -368,7 +407,7 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
                             if constexpr (kj + KD < Keep::count(K)) kring[kj % KD] = my_kept[(kj + KD) * kLanes];
                         } else if constexpr (sq + D < Keep::streamed_len(K)) {
                             asm volatile("" : "+v"(lane_offset) : "v"(acc));
-                            ring[sq % D] = load_word<Real, Streamed>(genomes, lane_offset,
+                            ring[sq % D] = load_word<Real>(genomes, lane_offset,
                                                                      Plan::word_at(K, Keep::pos_of_streamed(K, sq + D)));
                         }
                     });
@@ -378,7 +417,14 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
                     } else {
 #pragma unroll
                         for (int j = r0; j < r1; ++j) xch[Plan::xch_row(layer) + j][lane] = out[j - r0];
+                        LD_STAMP(st_work)
+                        LD_STAMP_ADD(1 + 2 * layer, st_prev, st_work)
                         split_barrier();
+                        LD_STAMP(st_bar)
+                        LD_STAMP_ADD(2 + 2 * layer, st_work, st_bar)
+#ifdef LD_DIAG_STAMPS
+                        st_prev = st_bar;
+#endif
 #pragma unroll
                         for (int j = 0; j < n_out; ++j) act[j] = xch[Plan::xch_row(layer) + j][lane];
                     }
@@ -392,6 +438,10 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
 #pragma unroll
         for (int k = 0; k < LD_N_OUTPUTS; ++k) d.u[k] = dead ? d.u[k] : act[k];
     }
+#ifdef LD_DIAG_STAMPS
+    if (lane == 0 && blockIdx.x == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&ld_diag_cycles[wave][k], diag_sum[k]);
+#endif
     if (!dead0 && wave == 0) {
         // a laundered copy of the index: otherwise the 25 load addresses stay live in 50 registers through
         // the whole kernel just to be reused here
@@ -404,12 +454,13 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
     }
 }
 
-template <typename Real, bool Faithful, int L, int S, bool Streamed, int KeepKiB, int... H>
+template <typename Real, bool Faithful, int L, int S, int KeepKiB, int... H>
 int launch_fly_split(const ld_sim_params* sim, const ld_episode_params* ep, const double* coins, const double* walls,
                      const Real* genomes, Real* fstate, int32_t* istate, int64_t n, int64_t begin, int64_t end,
                      int32_t n_steps, hipStream_t stream)
 {
-    hipLaunchKernelGGL((fly_split_kernel<Real, Faithful, L, S, Streamed, KeepKiB, H...>), dim3(blocks_for(end - begin, 64) * S), dim3(64 * L), 0, stream,
+    static_assert(S == 1 || S == 2 || S == 3 || S == 4, "workgroups of 64, 32, 48 or 16 drones");
+    hipLaunchKernelGGL((fly_split_kernel<Real, Faithful, L, S, KeepKiB, H...>), dim3(blocks_for(end - begin, S == 3 ? 48 : 64 / S)), dim3(64 * L), 0, stream,
                        make_sim<Real>(*sim), make_ep<Real>(*ep), coins, walls,
                        reinterpret_cast<const GeneWord<Real>*>(genomes), fstate, istate, n, begin, end, n_steps);
     return check_launch("fly_split_kernel");
@@ -420,7 +471,5 @@ int launch_fly_split(const ld_sim_params* sim, const ld_episode_params* ep, cons
 // One function per unrolled spec (ld_split_<tag>.hip): dispatch on the wavefronts per block.
 #define LD_DECLARE_SPLIT(TAG, ...)                                                                                \
     int ld_u_split_f32_##TAG(const ld_sim_params*, const ld_episode_params*, const double*, const double*,        \
-                             const float*, float*, int32_t*, int64_t, int64_t, int64_t, int32_t, int32_t, hipStream_t); \
-    int ld_u_split_cached_f32_##TAG(const ld_sim_params*, const ld_episode_params*, const double*, const double*,  \
-                                    const float*, float*, int32_t*, int64_t, int64_t, int64_t, int32_t, hipStream_t, int32_t);
+                             const float*, float*, int32_t*, int64_t, int64_t, int64_t, int32_t, int32_t, hipStream_t);
 LD_FOR_EACH_UNROLLED(LD_DECLARE_SPLIT)

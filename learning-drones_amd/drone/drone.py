@@ -97,7 +97,7 @@ class Drone(ControlUnit):
         """One physics + integration step with crash / instability reward (drone.py:129-165)."""
         pop = self._population()
         pop.sim = self.quadcopter.sim_params(wind_speed)
-        pop.episode = EpisodeParams.reference(n_coins=pop.episode.n_coins)
+        pop.episode = EpisodeParams.reference(n_coins=pop.episode.n_coins, coin_respawn=bool(pop.episode.coin_respawn))
         pop.reset()
         pop.set_state(self._state12()[None], self._acc6()[None], self.thrust.reshape(1, 4))
         pop.measure()

@@ -41,23 +41,30 @@ class QuadcopterPhysics:
         return p
 
     def calculate_accelerations(self, rotation, wind_speed, thrust, lin_acc_drone_2_lab: bool = True):
-        """rotation (3,1) = roll, pitch, yaw; wind_speed (3,1); thrust (4,1) -> (lin_acc (3,1) in the lab
-        frame, rot_acc (3,1) Euler-angle accelerations), physical_model.py:75-122."""
-        if not lin_acc_drone_2_lab:
-            raise NotImplementedError("only lin_acc_drone_2_lab=True (what every caller in the reference passes) is built")
+        """rotation (3,1) = roll, pitch, yaw; wind_speed (3,1); thrust (4,1) -> (lin_acc (3,1), rot_acc (3,1)),
+        physical_model.py:75-122.  lin_acc_drone_2_lab=True (what every caller in the reference passes): linear
+        acceleration in the lab frame and Euler-angle accelerations; False: the pair in the drone's frame, before
+        Rot^T and the Euler-rate matrix are applied (:114-120).  Either way the call leaves the rotation matrix in
+        self.Rot (:90).  One launch of ld_accelerations_frames_*."""
         import torch
         from ... import _native
         _native.require_gpu()
         f64 = self.precision == "f64"
         dtype = torch.float64 if f64 else torch.float32
         dev = torch.device("cuda", torch.cuda.current_device())
-        ang = torch.as_tensor(np.asarray(rotation, dtype=np.float64).reshape(3, 1)).to(dev, dtype).contiguous()
-        thr = torch.as_tensor(np.asarray(thrust, dtype=np.float64).reshape(4, 1)).to(dev, dtype).contiguous()
-        lin = torch.empty((3, 1), dtype=dtype, device=dev)
-        rot = torch.empty((3, 1), dtype=dtype, device=dev)
-        fn = _native.lib().ld_accelerations_f64 if f64 else _native.lib().ld_accelerations_f32
+        host = np.concatenate([np.asarray(rotation, dtype=np.float64).reshape(3), np.asarray(thrust, dtype=np.float64).reshape(4)])
+        inp = torch.as_tensor(host).to(dev, dtype)                       # one upload: angle[3], thrust[4]
+        out = torch.empty((15,), dtype=dtype, device=dev)                # one download: lin[3], rot[3], Rot[9]
+        fn = _native.lib().ld_accelerations_frames_f64 if f64 else _native.lib().ld_accelerations_frames_f32
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         sim = self.sim_params(wind_speed)
-        _native.check(fn(C.byref(sim), C.c_void_p(ang.data_ptr()), C.c_void_p(thr.data_ptr()), C.c_void_p(lin.data_ptr()),
-                         C.c_void_p(rot.data_ptr()), 1, stream), "ld_accelerations")
-        return lin.double().cpu().numpy().reshape(3, 1), rot.double().cpu().numpy().reshape(3, 1)
+        size = inp.element_size()
+        _native.check(fn(C.byref(sim), C.c_void_p(inp.data_ptr()), C.c_void_p(inp.data_ptr() + 3 * size),
+                         C.c_void_p(out.data_ptr()), C.c_void_p(out.data_ptr() + 3 * size), C.c_void_p(out.data_ptr() + 6 * size),
+                         1 if lin_acc_drone_2_lab else 0, 1, stream), "ld_accelerations_frames")
+        res = out.double().cpu().numpy()
+        self.Rot = res[6:15].reshape(3, 3).copy()
+        lin = res[0:3].reshape(3, 1).copy()
+        if not lin_acc_drone_2_lab:
+            lin = lin.astype(np.float32)                                 # the reference's forces / m stays float32 (:98,:114)
+        return lin, res[3:6].reshape(3, 1).copy()

@@ -160,10 +160,12 @@ class DeviceEvolution:
     backends without a device all-to-all (gloo).  Collectives per generation: one all_gather_into_tensor
     of the 16-byte records, one broadcast of the elite genome when the global best improves, and the
     parent exchange above.  The all-to-all path has run on gloo-backed CPU tensors and in threaded
-    single-GPU rehearsals only; it is unverified on RCCL until a multi-GPU record exists."""
+    single-GPU rehearsals only; it is unverified on RCCL until a multi-GPU record exists, so the default is
+    exchange="allgather" (the two most ordinary collectives) and "alltoall" is opt-in; exchange_bytes() says what
+    either moves per generation."""
 
     def __init__(self, population: "ShardedPopulation", ga=None, seed: int = 0, engine: str = "auto",
-                 exchange: str = "alltoall", place: Optional[str] = None):
+                 exchange: str = "allgather", place: Optional[str] = None):
         from .params import GaParams
         if exchange not in ("alltoall", "allgather"):
             raise ValueError("exchange must be 'alltoall' or 'allgather'")
@@ -185,6 +187,16 @@ class DeviceEvolution:
         self.elite = None                      # W x 4 genome words of the best drone so far
         self.history = []
         self.slot_of = None                    # canonical drone index -> global genome slot (None = identity)
+
+    def exchange_bytes(self) -> int:
+        """Genome bytes one rank RECEIVES per generation for the parent exchange: all-gather = every other shard;
+        all-to-all = the distinct parents its children need that live elsewhere (about (W-1)/W of one shard: tournament
+        selection draws ~0.8 n_local distinct parents per rank)."""
+        pop = self.pop
+        if pop.world == 1:
+            return 0
+        shard = pop.local.genomes.numel() * pop.local.genomes.element_size()
+        return shard * (pop.world - 1) if self.exchange == "allgather" else int(shard * 0.8 * (pop.world - 1) / pop.world)
 
     def _gather_genomes(self):
         """All-gather variant of the parent exchange: every rank receives every shard."""

@@ -75,11 +75,14 @@ class EpisodeParams(C.Structure):
     ]
 
     @classmethod
-    def reference(cls, *, punish_time=False, reward_time=True, n_coins=1, n_walls=0, coin_respawn=True) -> "EpisodeParams":
+    def reference(cls, *, punish_time=False, reward_time=True, n_coins=1, n_walls=0, coin_respawn=None) -> "EpisodeParams":
         """drone/drone.py:12-17; punish_time / reward_time as in fly() (flight/__init__.py:41-44).
         coin_respawn=True continues the chain beyond the table by the reference's rule
         (flight/__init__.py:47-52: +(5, 2.5, 0), radius 1, value 1000), without bound; False ends the
-        chain with the table's last row (BASELINE's "1 coin" / "3 coins" / "5 coins" configurations)."""
+        chain with the table's last row (BASELINE's "1 coin" / "3 coins" / "5 coins" configurations).  None (the
+        default) = not stated: the field is set to the reference's behaviour (1) and `respawn_explicit` is False, so
+        that Population can tell a stated choice from the default (its precedence: its own coin_respawn argument, then
+        an episode block that states one, then "a coin table given explicitly is a finite chain")."""
         e = cls()
         e.reward_time = 2 * (int(bool(reward_time)) - int(bool(punish_time)))
         e.reward_crashed = -3000
@@ -89,7 +92,8 @@ class EpisodeParams(C.Structure):
         e.angle_vel_limit = 20.0
         e.z_floor, e.z_ceiling = 0.0, 80.0
         e.n_coins, e.n_walls = n_coins, n_walls
-        e.coin_respawn, e.reserved = int(bool(coin_respawn)), 0
+        e.coin_respawn, e.reserved = (1 if coin_respawn is None else int(bool(coin_respawn))), 0
+        e.respawn_explicit = coin_respawn is not None
         return e
 
 

@@ -55,7 +55,11 @@ class Population:
                  coin_respawn: Optional[bool] = None, specialise: Optional[bool] = None):
         """coins=None is the reference's episode: the first coin (5, 5, 10) and the unbounded respawn
         chain behind it (flight/__init__.py:25,47-52).  A coin table given explicitly is a finite chain
-        (nothing respawns after its last row) unless coin_respawn=True continues it by the reference rule.
+        (nothing respawns after its last row) unless coin_respawn=True -- the argument, or an `episode` built with
+        EpisodeParams.reference(coin_respawn=True) -- continues it by the reference rule.  (Beyond the table the kernels
+        compute last_row + k * (5, 2.5, 0), which equals the reference's repeated additions exactly when the last row's x
+        and y are multiples of 2.5, as in every table the reference's rule itself produces; for other tables the two can
+        differ in the last bit.)
         specialise=True compiles the unrolled float32 kernels for this layer spec if the library does not ship
         them (_native.specialise: hipcc at first use, cached; identical results, about twice the throughput of
         the run-time-spec kernels) and raises if that fails; False never does; None (the default) does it for
@@ -86,7 +90,13 @@ class Population:
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.sim = sim if sim is not None else SimParams.reference()
         if coin_respawn is None:
-            coin_respawn = bool(episode.coin_respawn) if (episode is not None and coins is None) else coins is None
+            # precedence: the coin_respawn argument; then an episode block that STATES its coin_respawn (built with
+            # EpisodeParams.reference(coin_respawn=...), filled by hand, or read back from a checkpoint); then the rule of
+            # the docstring: the default episode is the unbounded chain, an explicit table is a finite one
+            if episode is not None and getattr(episode, "respawn_explicit", True):
+                coin_respawn = bool(episode.coin_respawn)
+            else:
+                coin_respawn = coins is None
         coins = coin_chain_reference(1) if coins is None else np.ascontiguousarray(coins, np.float64).reshape(-1, COIN_STRIDE)
         if not 1 <= len(coins) <= MAX_COINS:
             raise ValueError(f"need 1..{MAX_COINS} coin rows")
@@ -336,10 +346,21 @@ class Population:
                                                                 C.byref(w), C.byref(m), C.byref(tile)),
                       "ld_fly_rollout_geometry_f32")
         if self.precision == "f64":             # the same timesteps per launch, one wavefront per block, no tiles
-            return {"steps_per_launch": k.value, "waves_per_block": 1, "launches": -(-int(timesteps) // k.value), "tile_drones": self.n}
-        cached = int(_native.lib().ld_fly_rollout_cached_drones_f32(C.byref(self.spec), self.n, int(timesteps)))
+            return {"steps_per_launch": k.value, "waves_per_block": 1, "launches": -(-int(timesteps) // k.value), "tile_drones": self.n,
+                    "kept_words": 0, "streamed_words": self.W}
+        kept, streamed = self.kept_words(w.value, min(k.value, int(timesteps)))
         return {"steps_per_launch": k.value, "waves_per_block": w.value, "launches": m.value, "tile_drones": tile.value,
-                "cached_drones": cached}
+                "kept_words": kept, "streamed_words": streamed}
+
+    def kept_words(self, waves_per_block: int, n_steps: int):
+        """(gene words per drone a launch keeps in LDS, gene words per drone it streams every timestep) for a launch
+        of `n_steps` timesteps in the geometry `waves_per_block` (ld_fly_steps_kept_words_f32)."""
+        if self.precision != "f32":
+            return 0, self.W
+        kept, streamed = C.c_int64(0), C.c_int64(0)
+        _native.check(_native.lib().ld_fly_steps_kept_words_f32(C.byref(self.spec), int(waves_per_block), int(n_steps),
+                                                                C.byref(kept), C.byref(streamed)), "ld_fly_steps_kept_words_f32")
+        return kept.value, streamed.value
 
     def auto_waves_per_block(self, drones: int, steps_per_launch: int) -> int:
         """Wavefronts per genome block the library chooses (waves_per_block = 0) for a launch of `drones` drones

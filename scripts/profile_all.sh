@@ -8,9 +8,9 @@ mkdir -p $out
 export TMPDIR=/tmp
 # page the image in and bring the GPU to its sustained clocks before anything is recorded (the first run on a fresh box is ~5 % slow)
 python3 bench.py --steps 10 --warmup 2 --no-extras > /dev/null 2>&1
-scripts/profile_config.sh c3                                                       # BASELINE config 3 (headline: four tiles of 16 384 drones)
-scripts/profile_config.sh c3_plain --tile-drones 16384                              # the same tiles, one kernel per launch (no part kept in L2)
-scripts/profile_config.sh c3_whole --tile-drones 65536                             # the same, all 65 536 drones per launch (HBM-bound)
+scripts/profile_config.sh c3                                                       # BASELINE config 3 (headline: whole-population launches, 136 KiB of genes per workgroup kept in LDS)
+scripts/profile_config.sh c3_hbm --no-lds-keep --tile-drones 65536                 # the same with nothing kept on chip: every timestep's genes from HBM
+scripts/profile_config.sh c3_tiles --no-lds-keep                                   # the round-2 rollout: Infinity-Cache tiles, nothing in LDS
 scripts/profile_config.sh c3_k1 --steps-per-launch 1 --waves-per-block 1 --tile-drones 65536   # the literal contract: one launch per timestep
 scripts/profile_config.sh shard8 --drones 8192                                     # 65 536-drone population over 8 GPUs: one shard
 scripts/profile_config.sh c4 --drones 32768 --timesteps 4000                       # config 4 shard

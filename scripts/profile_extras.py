@@ -2,7 +2,10 @@
 """Summaries of the non-PMC-traffic passes of scripts/profile_all.sh: effective shader clock of the headline
 kernel (GRBM_GUI_ACTIVE), SQ counters of the default bench's kernels, kernel stats of the default bench and of
 the traced configurations.  Run from the repo root after profile_all.sh's outputs were merged into gpurun_out/prof."""
-import collections, csv, glob, json, statistics
+import collections, csv, glob, json, os, statistics
+
+ROUND = int(os.environ.get("ROUND", "3"))
+R = f"r{ROUND:02d}"
 
 P = "gpurun_out/prof"
 
@@ -19,17 +22,16 @@ def last_json(path):
 rows = [r for r in load(f"{P}/c3_clock/**/*counter_collection.csv") if "fly_split_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "GRBM_GUI_ACTIVE"]
 durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
 clocks = [float(r["Counter_Value"]) / 8 / d for r, d in zip(rows, durs)]
-un, tr = last_json(f"{P}/c3_unprofiled.json"), json.load(open("profiles/r02_c3_pmc.json"))
-json.dump({"round": 2, "what": "effective shader clock of the headline kernel while rocprofv3 collects counters: GRBM_GUI_ACTIVE / 8 / kernel duration (MI355X_MICROARCH.md, DVFS give-back)",
+un, tr = last_json(f"{P}/c3_unprofiled.json"), json.load(open(f"profiles/{R}_c3_pmc.json"))
+json.dump({"round": ROUND, "what": "effective shader clock of the headline kernel while rocprofv3 collects counters: GRBM_GUI_ACTIVE / 8 / kernel duration (MI355X_MICROARCH.md, DVFS give-back)",
            "command": "rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-extras",
            "kernel": tr["kernel"][:80], "dispatches": len(rows),
            "effective_clock_ghz": {"mean": statistics.fmean(clocks), "min": min(clocks), "max": max(clocks)},
            "launch_us_in_this_pass": statistics.fmean(durs) / 1e3, "launch_us_kernel_trace_pass": tr["launch_us_profiled"],
            "launch_us_unprofiled_same_box": un["roofline"]["launch_us"],
-           "note": "rocprofv3 serialises kernels while it collects counters, so the two concurrent kernels of a launch (cached head on the side stream + streaming rest) appear here one after the other: launch_us_in_this_pass is their per-kernel average, not the launch; profiled and un-profiled launch durations of one box agree within its run-to-run noise (a few per cent); round 1's 6 % gap "
-                   "(71.8 vs 67.5 us) was measured on two different boxes of the pool: this round's un-profiled runs of one binary "
-                   "spread over 62.3-64.7 us per timestep (whole-population launches) across boxes"},
-          open("profiles/r02_c3_clock.json", "w"), indent=1)
+           "note": "profiled and un-profiled launch durations of one box agree within its run-to-run noise (a few per cent); boxes of the "
+                   "pool differ by a few per cent among themselves"},
+          open(f"profiles/{R}_c3_clock.json", "w"), indent=1)
 
 # ---- SQ counters of the default bench
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -39,7 +41,8 @@ for r in load(f"{P}/full_sq/**/*counter_collection.csv"):
     if key is None:
         continue
     if key == "fly_split_kernel":
-        key += " L=" + name.split("fly_split_kernel<float, false, ")[1].split(",")[0]
+        args = name.split("fly_split_kernel<float, false, ")[1].split(",")
+        key += f" L={args[0].strip()} S={args[1].strip()} keep={args[2].strip()}"
     agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for key, cs in agg.items():
@@ -51,9 +54,9 @@ for key, cs in agg.items():
              frac_wait_inst=d["SQ_WAIT_INST_ANY"] / wc, valu_per_wave=d["SQ_INSTS_VALU"] / d["SQ_WAVES"], lds_per_wave=d["SQ_INSTS_LDS"] / d["SQ_WAVES"],
              salu_per_wave=d["SQ_INSTS_SALU"] / d["SQ_WAVES"])
     out[key] = d
-json.dump({"round": 2, "command": "rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
-           "note": "per-dispatch means over the dispatches within 20 % of the kernel's largest SQ_WAVE_CYCLES (full live-population launches: the bench also flies random-genome populations whose launches are mostly frozen); SQ_* cycle counters are quad-cycles summed over waves (MI355X_MICROARCH.md); fly_split L=4: 64 timesteps of a 16 384-drone tile per launch, L=8: 64 timesteps of the 8 192-drone shard (two workgroups of 8 wavefronts per block), L=2: 64 timesteps of all 65 536 drones, L=1: one timestep of 65 536 drones; fly_resident: a whole 2 000-step episode of 65 536 drones per launch",
-           "kernels": out}, open("profiles/r02_sq_counters.json", "w"), indent=1)
+json.dump({"round": ROUND, "command": "rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
+           "note": "per-dispatch means over the dispatches within 20 % of the kernel's largest SQ_WAVE_CYCLES (full live-population launches: the bench also flies random-genome populations whose launches are mostly frozen); SQ_* cycle counters are quad-cycles summed over waves (MI355X_MICROARCH.md); fly_split L = wavefronts per workgroup, S = workgroups per 64-drone block (3: workgroups of 48 drones), keep = KiB of genes per workgroup kept in LDS; fly_resident: a whole 2 000-step episode of 65 536 drones per launch",
+           "kernels": out}, open(f"profiles/{R}_sq_counters.json", "w"), indent=1)
 
 # ---- kernel stats
 def stats(src_glob, dst, top):
@@ -64,9 +67,9 @@ def stats(src_glob, dst, top):
         w.writeheader()
         for r in rows[:top]:
             r = dict(r); r["Name"] = r["Name"][:140]; w.writerow(r)
-stats(f"{P}/full_trace/**/*kernel_stats.csv", "profiles/r02_bench_kernel_stats.csv", 20)
-for t in ("c3", "c3_whole", "c3_k1", "shard8", "c4", "c5"):
-    stats(f"{P}/{t}_trace/**/*kernel_stats.csv", f"profiles/r02_{t}_kernel_stats.csv", 8)
-print(json.load(open("profiles/r02_c3_clock.json"))["effective_clock_ghz"])
+stats(f"{P}/full_trace/**/*kernel_stats.csv", f"profiles/{R}_bench_kernel_stats.csv", 20)
+for t in ("c3", "c3_hbm", "c3_k1", "shard8", "c4", "c5"):
+    stats(f"{P}/{t}_trace/**/*kernel_stats.csv", f"profiles/{R}_{t}_kernel_stats.csv", 8)
+print(json.load(open(f"profiles/{R}_c3_clock.json"))["effective_clock_ghz"])
 for k, d in out.items():
     print(k, {c: round(v, 3) for c, v in d.items() if c.startswith("frac") or c.endswith("per_wave")})

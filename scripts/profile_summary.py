@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--out", required=True); ap.add_argument("--round", type=int, default=2)
 ap.add_argument("--kernel", required=True, help="substring of the kernel name")
 ap.add_argument("--trace"); ap.add_argument("--fetch"); ap.add_argument("--write"); ap.add_argument("--bench")
+ap.add_argument("--tcc", help="-d directory of the --pmc TCC_HIT_sum TCC_MISS_sum pass"); ap.add_argument("--sq", help="-d directory of the SQ counter pass")
 ap.add_argument("--cmd", default=""); ap.add_argument("--pmc-cmd", default="")
 a = ap.parse_args()
 
@@ -35,9 +36,9 @@ if a.bench:
                      "coins": bench["config"]["coins"], "timesteps": bench["config"]["timesteps"],
                      "timesteps_per_launch": r["timesteps_per_launch"], "wavefronts_per_block": r["wavefronts_per_block"],
                      "drones_per_launch": r.get("drones_per_launch", bench["config"]["population"] // bench["n_gpus"]),
-                     "cached_drones_per_launch": r.get("cached_drones_per_launch", 0)}
-    doc["bench_line_of_the_traced_run"] = {"launch_us_from_hip_events": r["launch_us"], "achieved_gbs": r["achieved"],
-                                           "frac": r["frac"], "value": bench["value"], "ms_per_step": bench["ms_per_step"]}
+                     "kept_words_per_drone": r.get("kept_words_per_drone", 0), "streamed_words_per_drone": r.get("streamed_words_per_drone")}
+    doc["bench_line_of_the_traced_run"] = {"launch_us_from_hip_events": r["launch_us"], "algorithmic_gbs": r.get("algorithmic_gbs"),
+                                           "bound": r.get("bound"), "frac": r["frac"], "value": bench["value"], "ms_per_step": bench["ms_per_step"]}
     doc["algorithmic_bytes_per_launch"] = r["bytes_per_launch"]
 if a.trace:
     ks = [r for r in rows(a.trace, "kernel_stats.csv") if a.kernel in r["Name"]]
@@ -48,14 +49,8 @@ if a.trace:
     doc["kernel_trace"] = {"calls": int(k["Calls"]), "average_ns": float(k["AverageNs"]), "min_ns": float(k["MinNs"]),
                            "max_ns": float(k["MaxNs"]), "percentage_of_gpu_time": float(k["Percentage"])}
     doc["launch_us_profiled"] = float(k["AverageNs"]) / 1e3
-    if bench and bench["roofline"].get("cached_drones_per_launch"):
-        # a "launch" of this configuration is two concurrent kernels (the tile's head with cacheable gene loads on the
-        # library's side stream, the rest streaming on the caller's): the longer one is the launch's duration
-        doc["concurrent_kernels_per_launch"] = [{"name": r["Name"][:120], "calls": int(r["Calls"]), "average_ns": float(r["AverageNs"])}
-                                                for r in sorted(ks, key=lambda r: -float(r["TotalDurationNs"]))[:2]]
     if bench:
-        doc["achieved_gbs_from_trace"] = doc["algorithmic_bytes_per_launch"] / float(k["AverageNs"])
-        doc["frac_from_trace"] = doc["achieved_gbs_from_trace"] / 8000.0
+        doc["algorithmic_gbs_from_trace"] = doc["algorithmic_bytes_per_launch"] / float(k["AverageNs"])
     doc["all_kernels"] = [{"name": r["Name"][:120], "calls": int(r["Calls"]), "average_ns": float(r["AverageNs"]),
                            "percentage": float(r["Percentage"])} for r in sorted(rows(a.trace, "kernel_stats.csv"),
                                                                                  key=lambda r: -float(r["TotalDurationNs"]))[:12]]
@@ -69,11 +64,8 @@ for name, d in (("FETCH_SIZE", a.fetch), ("WRITE_SIZE", a.write)):
             per_kernel.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
     vals = [v for vs in per_kernel.values() for v in vs]
     if vals:
-        # the first launches of a run include cold effects; keep them all, report the spread.  Where a launch is two
-        # concurrent kernels (see above) its traffic is the sum of the two kernels' means.
-        pair = bool(bench and bench["roofline"].get("cached_drones_per_launch")) and len(per_kernel) == 2
-        mean = sum(statistics.fmean(vs) for vs in per_kernel.values()) if pair else statistics.fmean(vals)
-        pmc[name] = {"dispatches": len(vals), "mean_kb": mean, "min_kb": min(vals), "max_kb": max(vals), "summed_over_two_kernels": pair}
+        # the first launches of a run include cold effects; keep them all, report the spread
+        pmc[name] = {"dispatches": len(vals), "mean_kb": statistics.fmean(vals), "min_kb": min(vals), "max_kb": max(vals)}
 if pmc:
     doc["pmc"] = pmc
     doc["gfx950_correction"] = ("FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads: read bytes = 2 x FETCH_SIZE x 1024 "
@@ -85,5 +77,32 @@ if pmc:
         doc["hbm_traffic_bytes_per_launch"] = rd + wr
         if bench:
             doc["traffic_over_algorithmic"] = (rd + wr) / doc["algorithmic_bytes_per_launch"]
+# any other counters, mean per dispatch of the matching kernel
+def counter_means(d):
+    acc = {}
+    for r in rows(d, "counter_collection.csv"):
+        if a.kernel in r["Kernel_Name"]:
+            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return {k: statistics.fmean(v) for k, v in acc.items()}
+
+per = {"fabric_bytes": doc.get("hbm_traffic_bytes_per_launch")}
+if a.tcc:
+    t = counter_means(a.tcc)
+    if "TCC_HIT_sum" in t and "TCC_MISS_sum" in t:
+        doc["tcc"] = t
+        per["l2_hit_rate"] = t["TCC_HIT_sum"] / max(t["TCC_HIT_sum"] + t["TCC_MISS_sum"], 1.0)
+if a.sq:
+    q = counter_means(a.sq)
+    doc["sq"] = q
+    if "SQ_INSTS_VALU" in q:
+        per["valu_wave_instructions"] = q["SQ_INSTS_VALU"]
+    if q.get("SQ_WAVE_CYCLES"):
+        per["sq_issue_fraction"] = q.get("SQ_ACTIVE_INST_ANY", 0.0) / q["SQ_WAVE_CYCLES"]
+        per["sq_wait_fraction"] = q.get("SQ_WAIT_ANY", 0.0) / q["SQ_WAVE_CYCLES"]
+        per["sq_issue_stall_fraction"] = q.get("SQ_WAIT_INST_ANY", 0.0) / q["SQ_WAVE_CYCLES"]
+doc["per_launch"] = per
+if "hbm_traffic_bytes_per_launch" in doc:
+    doc["counter_note"] = ("FETCH_SIZE / WRITE_SIZE sit on the L2s' memory side: they count what the L2s pass on to the fabric, "
+                           "Infinity-Cache hits included (MI355X_MICROARCH.md), not HBM bytes alone")
 json.dump(doc, open(a.out, "w"), indent=1)
 print(json.dumps({k: doc.get(k) for k in ("launch_us_profiled", "achieved_gbs_from_trace", "traffic_over_algorithmic")}))

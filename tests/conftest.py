@@ -73,6 +73,16 @@ def g8():
 
 
 @pytest.fixture
+def lib():
+    """The loaded libld_drones.so (ctypes); the ld_debug_* switches are back at their defaults when the test ends."""
+    from learning_drones_amd import _native
+    handle = _native.lib()
+    yield handle
+    handle.ld_debug_force_generic(0)
+    handle.ld_debug_lds_keep(-1)
+
+
+@pytest.fixture
 def generic_kernels():
     """generic_kernels(True) routes every layer spec to the run-time-spec kernels (ld_debug_force_generic);
     the unrolled specialisations are back when the test ends."""

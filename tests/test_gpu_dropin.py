@@ -365,11 +365,14 @@ def test_pid_policy_matches_reference_episodes(g4):
     assert np.array_equal(f32["coins"], out["coins"])
 
 
-def test_alltoall_parent_exchange_equals_allgather():
+@pytest.mark.parametrize("permuted", [False, True])
+def test_alltoall_parent_exchange_equals_allgather(permuted):
     """Multi-GPU generation step, both exchange variants, simulated on one GPU with one thread per
     virtual rank and a mailbox standing in for the collective: breeding from the fetched distinct
     parents (all-to-all) must give exactly the children that breeding from the all-gathered shards
-    gives, and those must equal the single-population result."""
+    gives, and those must equal the single-population result.  permuted: the previous generation was placed
+    out of canonical order (place="parent"), so the selected canonical parents are translated to global SLOT
+    indices (slot_of) before owner = slot // n_local is computed -- same children."""
     import threading
     import torch
     from learning_drones_amd.parallel import exchange_parent_genomes
@@ -387,12 +390,27 @@ def test_alltoall_parent_exchange_equals_allgather():
     whole.breed(fitness, ga, elite=elite)
     want = whole.get_genomes().cpu().numpy()
 
+    slot_of, by_slot = None, genes
+    if permuted:
+        perm = rng.permutation(n)
+        slot_of = torch.as_tensor(perm, dtype=torch.int64, device="cuda")          # canonical index -> slot
+        by_slot = np.empty_like(genes)
+        by_slot[perm] = genes
     shards = []
     for r in range(world):
         p = Population(n_local, hidden)
-        p.set_genomes(genes[r * n_local:(r + 1) * n_local])
+        p.set_genomes(by_slot[r * n_local:(r + 1) * n_local])
         shards.append(p)
     original = [p.genomes.clone() for p in shards]
+    # the all-gather variant: every rank breeds from all the shards back to back (ld_ga_breed's segments)
+    gathered = torch.cat(original, dim=0)
+    for r in range(world):
+        shards[r].breed(fitness, ga, elite=elite, child_begin=r * n_local, src=gathered, n_per_segment=n_local, n_segments=world,
+                        slot_of=slot_of)
+    got_gather = np.concatenate([p.get_genomes().cpu().numpy() for p in shards])
+    assert np.array_equal(got_gather, want)
+    for r in range(world):
+        shards[r].genomes = original[r].clone()
 
     class ThreadComm:
         box, barrier = {}, threading.Barrier(world)
@@ -412,7 +430,7 @@ def test_alltoall_parent_exchange_equals_allgather():
     def run(r):
         try:
             torch.cuda.set_device(0)
-            shards[r].breed(fitness, ga, elite=elite, child_begin=r * n_local,
+            shards[r].breed(fitness, ga, elite=elite, child_begin=r * n_local, slot_of=slot_of,
                             fetch_parents=lambda parents: exchange_parent_genomes(original[r], n_local, parents, ThreadComm(r)))
         except Exception as e:                                         # surfaced below
             errors.append(e)

@@ -109,7 +109,7 @@ def test_checkpoint_keeps_physics_and_episode_blocks(Population, torch, tmp_path
     hidden, n = (16, 16), 130
     genes = _hover_genes(hidden, n, sigma=0.004, seed=3)
     sim = SimParams.reference(wind=(0.4, -0.2, 0.1), mass_payload=0.03, x_payload=0.02, y_payload=-0.01, dt=0.008)
-    ep = EpisodeParams.reference(punish_time=True, reward_time=False)
+    ep = EpisodeParams.reference(punish_time=True, reward_time=False, coin_respawn=False)      # a finite coin table
     ep.z_ceiling, ep.angle_limit = 30.0, 0.6
     walls = np.array([[6.0, 4.0, 8.0, 7.0, 8.0, 12.0]])
 
@@ -243,9 +243,8 @@ def _replicated(hidden, m, n, seed):
 
 def test_full_size_config4_shard(Population, torch):
     """One GPU's share of BASELINE config 4: 32 768 drones x 4 000 steps, 15-32-32-4, 3-coin chain (the
-    launch geometry this shard gets: two tiles of 16 384 drones, 64 timesteps per launch, the first 4 288 drones (28 MB of genes) of
-    each tile flown with cacheable gene loads on the library's side stream, the rest streaming with 8 wavefronts
-    per block).  Size-independent
+    launch geometry this shard gets: 64 timesteps per launch, all 32 768 drones in one launch, two workgroups of 8 wavefronts per
+    genome block, each keeping 136 KiB = 268 of its 32 drones' 428 streamed gene words in LDS for the launch).  Size-independent
     properties: genomes replicated from a 256-drone population under a random permutation give the
     permuted small-population results bit for bit; a re-run is bit-identical; one launch per timestep
     and the resident engine give the same records."""
@@ -259,13 +258,14 @@ def test_full_size_config4_shard(Population, torch):
     pop = Population(n, hidden, coins=coins)
     pop.set_genomes(torch.as_tensor(genes_m, dtype=torch.float32, device="cuda")[torch.as_tensor(src, device="cuda")])
     geo = pop.rollout_geometry(T)
-    assert geo == {"steps_per_launch": 64, "waves_per_block": 8, "launches": 126, "tile_drones": 16384, "cached_drones": 4288}
+    assert geo == {"steps_per_launch": 64, "waves_per_block": 16, "launches": 63, "tile_drones": 32768, "kept_words": 268, "streamed_words": 160}
     pop.fly(T)
     got = pop.results()
     for f in ("reward", "flight_time", "coins", "crashed", "distance_to_coin"):
         assert np.array_equal(got[f], want[f][src]), f
     rec = pop.records.clone()
-    for kw in (dict(steps_per_launch=1), dict(tile_drones=n), dict(tile_drones=4096 + 64, waves_per_block=2), dict(engine="resident"), {}):
+    for kw in (dict(steps_per_launch=1), dict(tile_drones=16384, waves_per_block=8), dict(tile_drones=4096 + 64, waves_per_block=2),
+               dict(waves_per_block=11), dict(engine="resident"), {}):
         pop.reset()
         pop.fly(T, **kw)
         assert torch.equal(pop.records, rec), kw
@@ -618,29 +618,35 @@ def test_bench_two_ranks_on_one_gpu_rehearses_the_multi_gpu_flow():
     assert "cpu_baseline" not in d                                        # rank 0 at N = 1 only
 
 
-def test_cached_tile_head_on_the_side_stream_is_bit_identical(Population, torch):
-    """The default rollout of a population of >= 16 384 drones of 32-32 flies the head of each tile (28 MB of genes) with
-    cacheable gene loads in a second launch on a side stream of the library's, concurrently with the streaming rest: a
-    ragged population (one full tile + a short one), walls, coins collected, crashes -- state, bookkeeping and
-    records equal the same tiles flown plainly (one kernel per launch), run after run, also from a non-default
-    stream of the caller's, and work enqueued behind fly() sees the finished episode."""
+def test_kept_genes_are_bit_identical_on_a_ragged_population(Population, torch, lib):
+    """Launches of 8 timesteps or more keep 136 KiB of every workgroup's genes in LDS (fly_split_kernel<..., 136, ...>): a
+    ragged population (not a multiple of 64, of 48 or of the tile), walls, coins collected, crashes -- state, bookkeeping
+    and records equal the same episode flown without the kept genes (ld_debug_lds_keep(0): Infinity-Cache tiles), in every
+    geometry that keeps (workgroups of 64, 48, 32, 16 drones), run after run, also from a non-default stream of the
+    caller's, and work enqueued behind fly() sees the finished episode."""
     hidden, m, T = (32, 32), 256, 330
-    n = 2 * 16384 + 16384 + 192                                           # three tiles; the last one is too short for a cached head
+    n = 2 * 16384 + 16384 + 192 + 37
     genes_m, src = _replicated(hidden, m, n, seed=11)
     walls = np.array([[3.0, 3.0, 8.0, 4.5, 7.0, 12.0]])
     pop = Population(n, hidden, walls=walls, coins=coin_chain_reference(2))
     pop.set_genomes(torch.as_tensor(genes_m, dtype=torch.float32, device="cuda")[torch.as_tensor(src, device="cuda")])
     geo = pop.rollout_geometry(T)
-    assert geo["tile_drones"] == 16384 and geo["cached_drones"] == 4288 and geo["waves_per_block"] == 8
-    pop.fly(T, tile_drones=16384)                                         # explicit geometry: one kernel per launch
+    assert geo["tile_drones"] == n and geo["waves_per_block"] == 16 and geo["kept_words"] == 268
+    assert lib.ld_debug_lds_keep(0) == -1
+    try:
+        assert pop.rollout_geometry(T)["tile_drones"] == 16384 and pop.rollout_geometry(T)["kept_words"] == 0
+        pop.fly(T)                                                        # nothing kept: tiles, four wavefronts per block
+    finally:
+        assert lib.ld_debug_lds_keep(-1) == 0
     want = (pop.fstate.clone(), pop.istate.clone(), pop.records.clone())
     crashed = (want[1][2] & 1).bool()
     assert crashed.any() and not crashed.all() and int(want[1][1].max()) >= 1
-    for rep in range(3):
+    for rep, kw in enumerate(({}, {}, dict(waves_per_block=8), dict(waves_per_block=11), dict(waves_per_block=32),
+                              dict(waves_per_block=11, tile_drones=12288), dict(steps_per_launch=9), dict(steps_per_launch=7))):
         pop.reset()
-        pop.fly(T)
+        pop.fly(T, **kw)
         summed = pop.records.sum(dim=0)                                   # enqueued behind fly() on the same stream
-        assert torch.equal(pop.fstate, want[0]) and torch.equal(pop.istate, want[1]) and torch.equal(pop.records, want[2]), rep
+        assert torch.equal(pop.fstate, want[0]) and torch.equal(pop.istate, want[1]) and torch.equal(pop.records, want[2]), (rep, kw)
         assert torch.equal(summed, want[2].sum(dim=0))
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):                                         # the caller's own stream
@@ -650,14 +656,60 @@ def test_cached_tile_head_on_the_side_stream_is_bit_identical(Population, torch)
     assert torch.equal(pop.fstate, want[0]) and torch.equal(pop.records, want[2])
 
 
+def test_two_populations_from_two_threads_and_two_streams(Population, torch):
+    """SURVEY 8b "Ownership / Threading": the library keeps no per-population, per-stream or per-thread launch state (it
+    owns no stream and allocates nothing), so two populations flown at once -- from one host thread on two streams, and
+    from two host threads -- give exactly what each gives alone."""
+    import threading
+    from bench import make_genomes
+    T = 300
+    pops, want = [], []
+    for k, (n, hidden) in enumerate(((16384 + 64, (32, 32)), (8192, (16, 16)))):
+        p = Population(n, hidden, coins=coin_chain_reference(3))
+        p.set_genomes(make_genomes(torch, n, hidden, p.device, k))
+        p.fly(T)
+        want.append((p.fstate.clone(), p.records.clone()))
+        pops.append(p)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for p, st in zip(pops, streams):                                      # one thread, two streams, nothing waits in between
+        with torch.cuda.stream(st):
+            p.reset()
+            p.fly(T)
+    torch.cuda.synchronize()
+    for p, w in zip(pops, want):
+        assert torch.equal(p.fstate, w[0]) and torch.equal(p.records, w[1])
+    errors = []
+
+    def worker(p, st):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(st):
+                for _ in range(3):
+                    p.reset()
+                    p.fly(T)
+            st.synchronize()
+        except Exception as e:                                            # surfaced below
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(p, st)) for p, st in zip(pops, streams)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    for p, w in zip(pops, want):
+        assert torch.equal(p.fstate, w[0]) and torch.equal(p.records, w[1])
+
+
 def test_rollout_is_capturable_in_a_hip_graph(Population, torch):
-    """ld_fly_rollout_f32 enqueues everything from C on the caller's stream (and forks / joins its side stream by
-    events), so a whole episode can be captured into a HIP graph and replayed: same records."""
+    """ld_fly_rollout_f32 enqueues everything from C on the caller's stream (the library owns no stream), so a whole
+    episode can be captured into a HIP graph and replayed: same records."""
     from bench import make_genomes
     n, T = 16384, 200
     pop = Population(n, (32, 32), coins=coin_chain_reference(3))
     pop.set_genomes(make_genomes(torch, n, (32, 32), pop.device, 0))
-    assert pop.rollout_geometry(T)["cached_drones"] > 0                   # the captured episode includes the side stream
+    assert pop.rollout_geometry(T)["kept_words"] > 0                      # the captured launches keep genes in LDS
     pop.fly(T)
     want = pop.records.clone()
     pop.reset()
@@ -672,3 +724,55 @@ def test_rollout_is_capturable_in_a_hip_graph(Population, torch):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(pop.records, want)
+
+
+# ------------------------------------------------------------------------------------------- both frames
+def test_accelerations_in_both_frames_match_the_reference(torch, lib, g8):
+    """calculate_accelerations(lin_acc_drone_2_lab=False) and the self.Rot it leaves behind (physical_model.py:90,
+    :114-120; golden G8, with wind and with the payload parameter set): the float64 kernel reproduces the reference's
+    body-frame pair and rotation matrix to rounding, the float32 closed form to 1e-3 of the scale; the lab-frame pair
+    of the same entry point equals ld_accelerations_* bit for bit; and the QuadcopterPhysics shim returns what the
+    reference's method returns, shapes and self.Rot included."""
+    import ctypes as C
+    from learning_drones_amd.drone.quadcopter import QuadcopterPhysics
+    from test_oracle_golden import frames_sim
+    for tag in ("plain", "payload"):
+        ang, thr, wind = g8[f"{tag}_angle"], g8[f"{tag}_thrust"], g8[f"{tag}_wind"]
+        sim = frames_sim(g8, tag)
+        for w in np.unique(wind, axis=0)[:40]:                        # the wind is uniform per launch
+            rows = np.where((wind == w).all(axis=1))[0]
+            sim.wind[:] = list(w)
+            n = len(rows)
+            for sfx, dtype, tol in (("f64", torch.float64, 1e-12), ("f32", torch.float32, 1e-3)):
+                a = torch.as_tensor(ang[rows].T.copy(), dtype=dtype, device="cuda").contiguous()
+                u = torch.as_tensor(thr[rows].T.copy(), dtype=dtype, device="cuda").contiguous()
+                out = {}
+                for lab in (0, 1):
+                    lin, rot = torch.empty((3, n), dtype=dtype, device="cuda"), torch.empty((3, n), dtype=dtype, device="cuda")
+                    mat = torch.empty((9, n), dtype=dtype, device="cuda")
+                    rc = getattr(lib, f"ld_accelerations_frames_{sfx}")(C.byref(sim), a.data_ptr(), u.data_ptr(), lin.data_ptr(),
+                                                                        rot.data_ptr(), mat.data_ptr(), lab, n, None)
+                    assert rc == 0
+                    out[lab] = (lin.double().cpu().numpy().T, rot.double().cpu().numpy().T, mat.double().cpu().numpy().T.reshape(n, 3, 3))
+                scale = lambda ref: np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1.0)
+                for lab, key in ((0, "body"), (1, "lab")):
+                    ok = np.abs(np.cos(ang[rows][:, 1])) > 0.05 if (lab and sfx == "f32") else np.ones(n, bool)   # away from the tan(pitch) pole
+                    for got, ref in ((out[lab][0], g8[f"{tag}_{key}_lin"][rows]), (out[lab][1], g8[f"{tag}_{key}_rot"][rows])):
+                        assert np.max(np.abs(got - ref)[ok] / scale(ref)[ok]) < tol, (tag, sfx, key)
+                    assert np.max(np.abs(out[lab][2] - g8[f"{tag}_Rot"][rows])) < (1e-15 if sfx == "f64" else 1e-6)
+                if sfx == "f64" and n > 50:                            # the reference keeps forces / m in float32: the same float32 values
+                    assert np.mean(out[0][0] == g8[f"{tag}_body_lin"][rows]) > 0.99   # (the device's sin / cos differ from libm's in the last bit now and then)
+                lin2, rot2 = torch.empty((3, n), dtype=dtype, device="cuda"), torch.empty((3, n), dtype=dtype, device="cuda")
+                assert getattr(lib, f"ld_accelerations_{sfx}")(C.byref(sim), a.data_ptr(), u.data_ptr(), lin2.data_ptr(), rot2.data_ptr(), n, None) == 0
+                assert np.array_equal(lin2.double().cpu().numpy().T, out[1][0]) and np.array_equal(rot2.double().cpu().numpy().T, out[1][1])
+    qp = QuadcopterPhysics()
+    assert qp.Rot.shape == (3, 3)
+    for i in (0, 120, 250):
+        col = lambda v: np.asarray(v, dtype=np.float64).reshape(-1, 1)
+        lin, rot = qp.calculate_accelerations(col(g8["plain_angle"][i]), col(g8["plain_wind"][i]), col(g8["plain_thrust"][i]), False)
+        assert lin.shape == (3, 1) and rot.shape == (3, 1) and lin.dtype == np.float32
+        assert np.allclose(lin.ravel().astype(np.float64), g8["plain_body_lin"][i], rtol=2e-7) and np.allclose(rot.ravel(), g8["plain_body_rot"][i], rtol=1e-13)
+        assert np.allclose(qp.Rot, g8["plain_Rot"][i], rtol=0, atol=1e-15)
+        lin, rot = qp.calculate_accelerations(col(g8["plain_angle"][i]), col(g8["plain_wind"][i]), col(g8["plain_thrust"][i]), True)
+        assert np.allclose(lin.ravel(), g8["plain_lab_lin"][i], rtol=1e-12, atol=1e-12) and np.allclose(rot.ravel(), g8["plain_lab_rot"][i], rtol=1e-12, atol=1e-12)
+

@@ -26,7 +26,7 @@ def test_header_and_library_agree(lib):
     assert declared == set(_native.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ld_version() == _native.ABI_VERSION == 2
+    assert lib.ld_version() == _native.ABI_VERSION == 3
     assert b"spec" in lib.ld_strerror(-2)
 
 
@@ -170,7 +170,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ld_ga_select(C.byref(ga), C.byref(spec), None, 8, 0, 8, fake, fake, None) == NULL
     steps = lib.ld_fly_steps_f32                                 # multi-wavefront / multi-step fused launch
     assert steps(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, 8, -1, 0, None) == SIZE
-    assert steps(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, 8, 4, 3, None) == SIZE      # waves not 0/1/2/4/8/16/32
+    assert steps(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, 8, 4, 3, None) == SIZE      # waves not 0/1/2/4/8/11/16/32
     assert steps(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, fake, fake, fake, 0, 4, 8, None) == OK
     assert steps(C.byref(sim), C.byref(ep), C.byref(spec), fake, None, odd, fake, fake, 8, 4, 8, None) == ALIGN
     assert steps(C.byref(sim), C.byref(ep), C.byref(MlpSpec.from_hidden((12,))), fake, None, fake, fake, fake, 8, 4, 4, None) == SPEC   # run-time spec: one wavefront per block only
@@ -181,19 +181,35 @@ def test_argument_validation_without_gpu(lib):
     k, w, m, tile = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
     geo = lambda h, n, T: (lib.ld_fly_rollout_geometry_f32(C.byref(MlpSpec.from_hidden(h)), n, T, C.byref(k), C.byref(w), C.byref(m),
                                                             C.byref(tile)), k.value, w.value, m.value, tile.value)
-    # config 3: 446 MB of genes > Infinity Cache -> four tiles of 16 384 drones (111 MB each), 4 wavefronts per block
-    assert geo((32, 32), 65536, 2000) == (OK, 64, 8, 128, 16384) and geo((32, 32), 8192, 2000) == (OK, 64, 16, 32, 8192)   # 8: the streaming part of a tile whose head is kept in L2
-    assert geo((32, 32), 32768, 4000) == (OK, 64, 8, 126, 16384)           # config 4 shard: 223 MB -> two tiles
-    assert geo((32, 32), 16384, 2000) == (OK, 64, 8, 32, 16384)
+    # nets of up to 512 gene words that split evenly over 8 wavefronts keep 136 KiB of genes per workgroup in LDS: no tiles,
+    # workgroups of 8 wavefronts, as many per block as keep the resident workgroups' stream within the L2s (32-32: two)
+    assert geo((32, 32), 65536, 2000) == (OK, 64, 16, 32, 65536) and geo((32, 32), 8192, 2000) == (OK, 64, 16, 32, 8192)
+    assert geo((32, 32), 32768, 4000) == (OK, 64, 16, 63, 32768)          # config 4 shard
+    assert geo((32, 32), 16384, 2000) == (OK, 64, 16, 32, 16384) and geo((32, 32), 1024, 2000) == (OK, 64, 32, 32, 1024)
+    assert geo((16, 16), 65536, 2000) == (OK, 64, 8, 32, 65536) and geo((16, 16), 1024, 2000) == (OK, 64, 32, 32, 1024)   # config 2
+    kept, streamed = C.c_int64(), C.c_int64()
+    words = lambda h, w, steps: (lib.ld_fly_steps_kept_words_f32(C.byref(MlpSpec.from_hidden(h)), w, steps, C.byref(kept), C.byref(streamed)),
+                                 kept.value, streamed.value)
+    assert words((32, 32), 8, 64)[1:] == (132, 296) and words((32, 32), 16, 64)[1:] == (268, 160) and words((32, 32), 11, 64)[1:] == (176, 252)
+    assert words((32, 32), 32, 64)[1:] == (428, 0) and words((16, 16), 8, 64)[1:] == (132, 24)   # everything / nearly everything kept (three words straddle two wavefronts' rows)
+    assert words((32, 32), 16, 4)[1:] == (0, 425) and words((32, 32), 4, 64)[1:] == (0, 425)   # short launches and other geometries keep nothing
+    assert words((64, 64, 64), 8, 64)[1:] == (0, 2401) and words((32, 32), 3, 64)[0] == SIZE
+    # ... and without the kept genes (ld_debug_lds_keep(0)): tiles of ~112 MB of genes that the Infinity Cache holds
+    assert lib.ld_debug_lds_keep(0) == -1
+    assert geo((32, 32), 65536, 2000) == (OK, 64, 4, 128, 16384) and geo((32, 32), 32768, 4000) == (OK, 64, 4, 126, 16384)
+    assert words((32, 32), 16, 64)[1:] == (0, 425)
+    assert lib.ld_debug_lds_keep(-1) == 0
     assert geo((64, 64, 64), 131072, 4000) == (OK, 64, 8, 63, 131072)     # 38 KB of genes per drone: a tile could not fill the chip; two workgroups of 4
     assert geo((64, 64, 64), 8192, 100) == (OK, 64, 8, 2, 8192) and geo((12,), 1000, 50) == (OK, 64, 1, 1, 1000)   # run-time spec: one wavefront per block, 64 timesteps per launch
     assert geo((10, 10), 65536, 2000) == (OK, 64, 2, 32, 65536)           # 82 MB: fits as it is; 10 rows split evenly over 2 wavefronts only
-    assert geo((10, 10), 1024, 2000)[2] == 2 and geo((8, 8), 1024, 2000)[2] == 4 and geo((16, 16), 65536, 2000)[2] == 8
+    assert geo((10, 10), 1024, 2000)[2] == 2 and geo((8, 8), 1024, 2000)[2] == 4
     assert geo((10, 10), 1048576, 100)[4] == 65536
     assert lib.ld_fly_rollout_geometry_f32(C.byref(spec), 8, 8, None, None, None, None) == NULL
     for sfx in ("f32", "f64"):
         acc = getattr(lib, f"ld_accelerations_{sfx}")
         assert acc(C.byref(sim), fake, fake, fake, None, 4, None) == NULL and acc(C.byref(sim), None, None, None, None, -1, None) == SIZE
+        frames = getattr(lib, f"ld_accelerations_frames_{sfx}")
+        assert frames(C.byref(sim), fake, fake, fake, None, None, 0, 4, None) == NULL and frames(C.byref(sim), None, None, None, None, None, 1, 0, None) == OK
     assert lib.ld_debug_force_generic(1) == 0 and lib.ld_debug_force_generic(0) == 1
     res = lib.ld_fly_rollout_resident_f32
     unsupported = MlpSpec.from_hidden((12,))                 # no unrolled / resident specialisation
@@ -248,10 +264,11 @@ def test_no_fused_step_kernel_runs_out_of_scratch():
     repo = Path(__file__).resolve().parent.parent
     out = subprocess.run([sys.executable, str(repo / "scripts" / "audit_scratch.py")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
-    assert "fly_split_kernel<float, false, 4, 1, true, 0, 32, 32>" in out.stdout and "fly_split_kernel<float, false, 8, 2, false, 0, 32, 32>" in out.stdout
-    # the variants that keep 136 KiB of a workgroup's genes in LDS: none of those the launch policy picks uses scratch
+    assert "fly_split_kernel<float, false, 4, 1, 0, 32, 32>" in out.stdout and "fly_split_kernel<float, false, 8, 2, 0, 32, 32>" in out.stdout
+    # the variants that keep 136 KiB of a workgroup's genes in LDS (workgroups of 64, 32, 48 and 16 drones): none of
+    # those the launch policy picks uses scratch
     for spec in ("32, 32", "16, 16", "24, 24", "16", "32"):
-        for geometry in ("8, 1, true", "8, 2, true", "8, 4, true", "8, 2, false"):
+        for geometry in ("8, 1", "8, 2", "8, 3", "8, 4"):
             line = [l for l in out.stdout.splitlines() if l.startswith(f"fly_split_kernel<float, false, {geometry}, 136, {spec}>")]
             assert len(line) == 1 and line[0].endswith("scratch 0"), (spec, geometry, line)
     assert "fly_resident_kernel" in out.stdout

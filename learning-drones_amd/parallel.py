@@ -30,35 +30,35 @@ def shard_counts(n_total: int, world: int):
     return [shard_bounds(n_total, world, r)[1] - shard_bounds(n_total, world, r)[0] for r in range(world)]
 
 
-def gather_records(local_records, n_total: int, process_group=None):
-    """All-gather the per-drone result records ([n_local, 4] int32) into [n_total, 4] in global drone
-    order on every rank.  Works on any device/backend pair torch.distributed supports."""
-    import torch
-    import torch.distributed as dist
-    if process_group is None or dist.get_world_size(process_group) == 1:
-        return local_records
-    world = dist.get_world_size(process_group)
-    counts = shard_counts(n_total, world)
-    width = local_records.shape[1]
-    if len(set(counts)) == 1:
-        out = torch.empty((n_total, width), dtype=local_records.dtype, device=local_records.device)
-        dist.all_gather_into_tensor(out, local_records.contiguous(), group=process_group)
-        return out
-    pad = max(counts)
-    buf = torch.zeros((pad, width), dtype=local_records.dtype, device=local_records.device)
-    buf[: local_records.shape[0]] = local_records
-    parts = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(parts, buf, group=process_group)
-    return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
-
-
 class DistComm:
-    """Variable-size all-to-all over a torch.distributed group (RCCL on GPUs, gloo in CPU tests)."""
+    """The collectives this module needs, over a torch.distributed group (RCCL on GPUs, gloo in CPU tests).  Anything
+    with the same five members (rank, world, all_gather, all_to_all, broadcast, device_alltoall) can stand in for it:
+    the single-GPU tests run eight "ranks" as threads of one process over a mailbox (tests/conftest.py, ThreadComm),
+    because a GPU box admits only a few processes on its card at a time."""
 
     def __init__(self, group):
         import torch.distributed as dist
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        # gloo has no all-to-all on device tensors; nccl (= RCCL on ROCm) does.  Read from the backend's NAME, identically
+        # on every rank and before any collective is issued: probing with a try/except could let one rank fall back
+        # while another does not (collective errors surface asynchronously), after which the ranks would wait in
+        # different collectives.
+        self.device_alltoall = dist.get_backend(group) == "nccl"
+
+    def all_gather(self, tensor):
+        """Equal shards [k, ...] -> [world * k, ...] in rank order (ONE all_gather_into_tensor)."""
+        import torch
+        import torch.distributed as dist
+        out = torch.empty((self.world * tensor.shape[0],) + tuple(tensor.shape[1:]), dtype=tensor.dtype, device=tensor.device)
+        dist.all_gather_into_tensor(out, tensor.contiguous(), group=self.group)
+        return out
+
+    def broadcast(self, tensor, src: int):
+        """In place, from the group's rank `src`."""
+        import torch.distributed as dist
+        dist.broadcast(tensor, src=dist.get_global_rank(self.group, src), group=self.group)
+        return tensor
 
     def all_to_all(self, send):
         """send[r]: tensor for rank r (first dimension may differ per destination, trailing dimensions
@@ -74,6 +74,31 @@ class DistComm:
         dist.all_to_all_single(out, torch.cat(send).contiguous(), output_split_sizes=incoming,
                                input_split_sizes=[t.shape[0] for t in send], group=self.group)
         return list(out.split(incoming))
+
+
+def as_comm(group_or_comm):
+    """None (one rank), a communicator object as described at DistComm, or a torch.distributed process group."""
+    if group_or_comm is None or hasattr(group_or_comm, "all_gather"):
+        return group_or_comm
+    return DistComm(group_or_comm)
+
+
+def gather_records(local_records, n_total: int, process_group=None):
+    """All-gather the per-drone result records ([n_local, 4] int32) into [n_total, 4] in global drone
+    order on every rank.  Works on any device/backend pair torch.distributed supports."""
+    import torch
+    comm = as_comm(process_group)
+    if comm is None or comm.world == 1:
+        return local_records
+    counts = shard_counts(n_total, comm.world)
+    width = local_records.shape[1]
+    if len(set(counts)) == 1:
+        return comm.all_gather(local_records)
+    pad = max(counts)                                          # unequal shards: pad to the longest, gather, cut
+    buf = torch.zeros((pad, width), dtype=local_records.dtype, device=local_records.device)
+    buf[: local_records.shape[0]] = local_records
+    parts = comm.all_gather(buf).view(comm.world, pad, width)
+    return torch.cat([parts[r, :c] for r, c in enumerate(counts)], dim=0)
 
 
 def exchange_parent_genomes(genomes_local, n_local: int, parents_global, comm):
@@ -112,12 +137,9 @@ class ShardedPopulation:
     def __init__(self, n_total: int, hidden, *, process_group=None, device=None, **population_kwargs):
         from .population import Population
         self.n_total = int(n_total)
+        self.comm = as_comm(process_group)                     # a torch.distributed group, a communicator object, or None
         self.group = process_group
-        if process_group is None:
-            self.rank, self.world = 0, 1
-        else:
-            import torch.distributed as dist
-            self.rank, self.world = dist.get_rank(process_group), dist.get_world_size(process_group)
+        self.rank, self.world = (0, 1) if self.comm is None else (self.comm.rank, self.comm.world)
         self.begin, self.end = shard_bounds(self.n_total, self.world, self.rank)
         self.local = Population(self.end - self.begin, hidden, device=device, **population_kwargs)
 
@@ -130,7 +152,7 @@ class ShardedPopulation:
         int32 record tensor (global drone order) on every rank.  `geometry`: steps_per_launch /
         waves_per_block of Population.fly."""
         local = self.local.fly(timesteps, engine=engine, **geometry)
-        return gather_records(local, self.n_total, self.group)
+        return gather_records(local, self.n_total, self.comm)
 
     @staticmethod
     def records_to_numpy(records) -> np.ndarray:
@@ -200,15 +222,10 @@ class DeviceEvolution:
 
     def _gather_genomes(self):
         """All-gather variant of the parent exchange: every rank receives every shard."""
-        import torch
-        import torch.distributed as dist
         local = self.pop.local.genomes
         if self.pop.world == 1:
             return local, self.pop.local.n, 1
-        out = torch.empty((self.pop.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
-                          device=local.device)      # shards back to back = the segments of ld_ga_breed
-        dist.all_gather_into_tensor(out, local.contiguous(), group=self.pop.group)
-        return out, self.pop.local.n, self.pop.world
+        return self.pop.comm.all_gather(local), self.pop.local.n, self.pop.world      # shards back to back = the segments of ld_ga_breed
 
     def step(self, timesteps: int):
         """One generation.  Returns (best_score, global_best_score, records)."""
@@ -236,26 +253,19 @@ class DeviceEvolution:
             if owner == pop.rank:
                 elite.copy_(pop.local.genome_of(best_slot - pop.begin))
             if pop.world > 1:
-                import torch.distributed as dist
-                dist.broadcast(elite, src=dist.get_global_rank(pop.group, owner), group=pop.group)
+                pop.comm.broadcast(elite, owner)
             self.elite = elite
         self.ga.generation = self.generation
         if pop.world > 1 and pop.n_total % pop.world:
             raise ValueError("the device generation step needs equal shards (n_total divisible by the world size)")
         if pop.world > 1 and self.exchange == "alltoall" and not self._alltoall_checked:
-            # Chosen from the backend's NAME, identically on every rank and before any collective is
-            # issued: probing with a try/except could let one rank fall back while another does not
-            # (collective errors surface asynchronously), after which the ranks would wait in different
-            # collectives.  gloo has no all-to-all on device tensors; nccl (= RCCL on ROCm) does.
-            import torch.distributed as dist
-            if dist.get_backend(pop.group) != "nccl":
+            if not pop.comm.device_alltoall:                   # decided from the backend's name, identically on every rank (DistComm)
                 self.exchange = "allgather"
             self._alltoall_checked = True
         if pop.world > 1 and self.exchange == "alltoall":
             # only the selected parents travel (~1/W of an all-gather)
             pop.local.breed(fitness, self.ga, elite=self.elite, child_begin=pop.begin, lifetimes=lifetimes, slot_of=slot_of, place=place,
-                            fetch_parents=lambda parents: exchange_parent_genomes(pop.local.genomes, pop.local.n, parents,
-                                                                                  DistComm(pop.group)))
+                            fetch_parents=lambda parents: exchange_parent_genomes(pop.local.genomes, pop.local.n, parents, pop.comm))
         else:
             src, n_per_segment, n_segments = self._gather_genomes()
             pop.local.breed(fitness, self.ga, elite=self.elite, child_begin=pop.begin, src=src,
@@ -268,10 +278,7 @@ class DeviceEvolution:
             local_slot_of = torch.empty_like(order, dtype=torch.int64)
             local_slot_of[order.long()] = torch.arange(order.numel(), device=order.device) + pop.begin
             if pop.world > 1:
-                import torch.distributed as dist
-                full = torch.empty((pop.n_total,), dtype=torch.int64, device=order.device)
-                dist.all_gather_into_tensor(full, local_slot_of, group=pop.group)      # 8 bytes per drone
-                local_slot_of = full
+                local_slot_of = pop.comm.all_gather(local_slot_of)                     # 8 bytes per drone
             self.slot_of = local_slot_of
         pop.local.reset()                                             # Drone.reset for every child
         self.generation += 1

@@ -90,3 +90,66 @@ def generic_kernels():
     lib = _native.lib()
     yield lambda on: lib.ld_debug_force_generic(1 if on else 0)
     lib.ld_debug_force_generic(0)
+
+
+class ThreadComm:
+    """`world` "ranks" as threads of ONE process, with a mailbox and a barrier standing in for the collectives: the
+    communicator interface of learning_drones_amd.parallel.DistComm.  A GPU box admits only a few processes on its card
+    at a time, so the 8-rank shapes of BASELINE configs 4 and 5 are rehearsed this way (the torch.distributed code
+    path itself is covered with 2-4 gloo processes)."""
+
+    class Shared:
+        def __init__(self, world):
+            import threading
+            self.world, self.box, self.barrier = world, {}, threading.Barrier(world)
+
+    device_alltoall = True
+
+    def __init__(self, shared, rank):
+        self.shared, self.rank, self.world = shared, rank, shared.world
+
+    def _exchange(self, item):
+        self.shared.box[self.rank] = item
+        self.shared.barrier.wait()
+        items = [self.shared.box[r] for r in range(self.world)]
+        self.shared.barrier.wait()
+        return items
+
+    def all_gather(self, tensor):
+        import torch
+        return torch.cat(self._exchange(tensor.contiguous()), dim=0)
+
+    def broadcast(self, tensor, src):
+        items = self._exchange(tensor.clone() if self.rank == src else None)
+        tensor.copy_(items[src])
+        return tensor
+
+    def all_to_all(self, send):
+        items = self._exchange(list(send))
+        return [items[r][self.rank] for r in range(self.world)]
+
+
+def run_ranks(world, fn, timeout=1200):
+    """fn(comm) on `world` threads, one ThreadComm each; returns the results in rank order, re-raises the first error."""
+    import threading
+    shared, out, errors = ThreadComm.Shared(world), [None] * world, []
+
+    def body(r):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.set_device(0)
+            out[r] = fn(ThreadComm(shared, r))
+        except BaseException as e:                                        # surfaced below; release the others
+            errors.append(e)
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=timeout)
+    if errors:
+        raise errors[0]
+    return out
+

@@ -183,8 +183,11 @@ def test_accelerations_entry_point_and_shim(torch, g1):
     assert lin.shape == (3, 1) and rot.shape == (3, 1)
     assert np.max(np.abs(np.concatenate([lin, rot]).ravel() - acc[k]) / np.maximum(np.abs(acc[k]), 1.0)) < 1e-11
     assert d.quadcopter.G == pytest.approx(3.924) and d.quadcopter.c_f == 5 and d.quadcopter.m_c == 0.2
-    with pytest.raises(NotImplementedError):
-        d.quadcopter.calculate_accelerations(np.zeros((3, 1)), np.zeros((3, 1)), np.zeros((4, 1)), lin_acc_drone_2_lab=False)
+    # lin_acc_drone_2_lab=False: at rest and level the body frame is the lab frame (free fall, no rotation), and the call
+    # leaves the identity in self.Rot (test_accelerations_in_both_frames_match_the_reference has the reference's vectors)
+    lin, rot = d.quadcopter.calculate_accelerations(np.zeros((3, 1)), np.zeros((3, 1)), np.zeros((4, 1)), lin_acc_drone_2_lab=False)
+    assert lin.dtype == np.float32 and np.allclose(lin.ravel(), [0, 0, -9.81], rtol=1e-6) and not rot.any()
+    assert np.array_equal(d.quadcopter.Rot, np.identity(3))
     nn = d.controller                                                     # evolve/brain.py:26-39 helpers
     assert np.array_equal(nn.relu(np.array([[-1.0], [2.0], [0.0]])), [[0.0], [2.0], [0.0]]) and nn._relu(-3) == 0.0
     assert nn.sigmoid(0.0) == 0.5 and abs(nn.sigmoid(2.5) - 1 / (np.exp(-1.0) + 1)) < 1e-15
@@ -585,8 +588,15 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert d["vs_baseline"] is None and d["higher_is_better"] is True and "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 4096 * 200 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert r["launch_us"] > 0 and "traffic" in r
+    # every level the launch's bytes can come from is priced; `bound` names the one with the highest fraction, which is
+    # therefore the line's frac -- a fraction of the ceiling that binds, never above 1
+    assert {"hbm", "l2", "lds"} <= set(r["levels"]) and all(abs(v["frac"] - v["achieved"] / v["peak"]) < 1e-9 for v in r["levels"].values())
+    top = max(r["levels"].values(), key=lambda v: v["frac"])
+    assert r["frac"] == top["frac"] and r["achieved"] == top["achieved"] and r["peak"] == top["peak"] and 0 < r["frac"] <= 1.0
+    assert r["levels"]["hbm"]["peak"] == 8000.0 and r["unit"] in ("GB/s", "G wave-instructions/s")
+    assert r["launch_us"] > 0 and "traffic" in r and r["kept_words_per_drone"] == 428 and r["streamed_words_per_drone"] == 0   # 4 096 drones: 16 per workgroup
+    assert "roofline_hbm_bound" in d and d["one_timestep_per_launch"]["bound"] == "hbm"
+    assert "exchange_bytes_per_generation_per_rank" in d["generation"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["one_thread"]["cores"] == 1
     assert d["ranks_seen"] == [0] and d["records"]["rows"] == 4096

@@ -215,7 +215,7 @@ def main():
             geo.update(steps_per_launch=k, tile_drones=tile, launches=-(-n_local // tile) * -(-T // k))
             # the wavefronts per block the library picks for launches of `tile` drones (or the explicit value)
             geo["waves_per_block"] = args.waves_per_block or pop.local.auto_waves_per_block(tile, k)
-            geo["kept_words"], geo["streamed_words"] = pop.local.kept_words(geo["waves_per_block"], min(k, T))
+            geo["lds_words"], geo["register_words"], geo["streamed_words"] = pop.local.kept_words(geo["waves_per_block"], min(k, T))
 
         def episode():
             pop.local.reset()
@@ -247,11 +247,13 @@ def main():
         bytes_per_launch = (gene_bytes + launches_per_tile * state_bytes) / geo["launches"]
         steps_per_launch_avg = T * tiles / geo["launches"]                    # timesteps of the average launch
         drones_per_launch_avg = n_local / tiles
-        # where the average launch's gene bytes come from.  A gene word is 16 bytes; the launch keeps `kept_words` per drone
-        # in LDS (read from memory once per launch, from LDS every timestep) and requests `streamed_words` per drone and
-        # timestep from the L2s, which pass on to the fabric / HBM what they do not hold.
-        kept, streamed = geo["kept_words"], geo["streamed_words"]
-        lds_bytes = drones_per_launch_avg * steps_per_launch_avg * 16 * kept
+        # where the average launch's gene bytes come from.  A gene word is 16 bytes; per drone the launch keeps `lds_words` in
+        # LDS and `register_words` in registers (both read from memory once per launch; the LDS ones read back from LDS every
+        # timestep) and requests `streamed_words` per timestep from the L2s, which pass on to the fabric / HBM what they do
+        # not hold.
+        in_lds, in_regs, streamed = geo["lds_words"], geo["register_words"], geo["streamed_words"]
+        kept = in_lds + in_regs
+        lds_bytes = drones_per_launch_avg * steps_per_launch_avg * 16 * in_lds
         l2_request_bytes = drones_per_launch_avg * (steps_per_launch_avg * 16 * streamed + 16 * kept) + state_bytes / tiles
         # HBM, modelled: a launch's genes are new to the caches when they exceed the Infinity Cache between two launches
         # over the same drones (the next launch of a tile comes right behind it; of the whole population, after 446 MB)
@@ -263,19 +265,20 @@ def main():
             "hbm": {"bytes_per_launch": hbm_bytes, "source": "model: a launch's genes from HBM once (they exceed the Infinity Cache "
                     "between launches) + the state", "achieved": hbm_bytes / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"},
             "l2": {"bytes_per_launch": l2_request_bytes, "source": "model: the words the launch does not keep in LDS, requested "
-                   "from the L2s every timestep (+ the kept words once)", "achieved": l2_request_bytes / launch_s / 1e9,
+                   "or in registers, requested from the L2s every timestep (+ the kept words once per launch)", "achieved": l2_request_bytes / launch_s / 1e9,
                    "peak": L2_PEAK_GBS, "unit": "GB/s"},
-            "lds": {"bytes_per_launch": lds_bytes, "source": "model: the kept words, read back from LDS every timestep",
+            "lds": {"bytes_per_launch": lds_bytes, "source": "model: the words kept in LDS, read back every timestep (the words held "
+                    "in registers cost no traffic at all)",
                     "achieved": lds_bytes / launch_s / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s"},
         }
         roof = {"kernel": ("fly_split_kernel<float, %d wavefronts per block, %s KiB of genes kept in LDS, %s>"
-                           % (geo["waves_per_block"], "136" if kept else "0", "-".join(map(str, hidden)))
+                           % (geo["waves_per_block"], "136" if in_lds else "0", "-".join(map(str, hidden)))
                            if geo["steps_per_launch"] > 1 or geo["waves_per_block"] > 1 or pop.local.has_resident_engine()
                            else "fly_step_kernel<float, GenericNet> (run-time layer spec)"),
                 "launch_us": launch_ms * 1e3, "bytes_per_launch": bytes_per_launch, "algorithmic_gbs": bytes_per_launch / launch_s / 1e9,
                 "timesteps_per_launch": geo["steps_per_launch"], "wavefronts_per_block": geo["waves_per_block"],
                 "launches_per_episode": geo["launches"], "drones_per_launch": geo["tile_drones"], "tiles": tiles,
-                "kept_words_per_drone": kept, "streamed_words_per_drone": streamed,
+                "lds_words_per_drone": in_lds, "register_words_per_drone": in_regs, "kept_words_per_drone": kept, "streamed_words_per_drone": streamed,
                 "levels": levels,
                 "bytes_model": "algorithmic bytes per launch, averaged over the episode's launches: drones x (timesteps x 4P + 200): "
                                "genes once per timestep, the 25 state words read and written once per launch (they stay in registers "

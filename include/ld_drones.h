@@ -137,7 +137,11 @@ typedef struct ld_episode_params {
                                    episode.  0: the chain ends with the table (BASELINE's "1 coin" /
                                    "3 coins" / "5 coins" configurations): the last row stays the target
                                    of the controller and of the distance penalty, nothing more is
-                                   collected. */
+                                   collected.  (Beyond the table the kernels compute last row + k * (5, 2.5, 0),
+                                   which equals the reference's repeated additions bit for bit when the last
+                                   row's x and y are multiples of 2.5 -- every table the reference's own rule
+                                   produces; for other tables the two can differ in the last bit: parity
+                                   unpinned there.) */
     int32_t reserved;           /* 0 */
 } ld_episode_params;
 
@@ -268,8 +272,9 @@ int ld_fly_step_f64(const ld_sim_params *sim, const ld_episode_params *ep, const
  * instead of 200 bytes of state traffic per drone-step.  With n_steps >= 8, for nets of up to 512 gene words whose
  * hidden layers split evenly over 8 wavefronts, the workgroups of 8 wavefronts (waves_per_block 8, 11, 16, 32)
  * also KEEP 136 KiB of their drones' genes in the CU's LDS for the whole launch (loaded once, read back from LDS
- * every timestep: 32 / 43 / 64 / 100 % of a 32-32 net's genes at 64 / 48 / 32 / 16 drones per workgroup), so only
- * the rest is re-streamed; ld_fly_steps_kept_words_f32 reports the split.  Results are bit-identical to n_steps
+ * every timestep: 31 / 41 / 63 / 100 % of a 32-32 net's genes at 64 / 48 / 32 / 16 drones per workgroup) and hold up
+ * to 12-14 more gene words per wavefront in registers, so only the rest is re-streamed (32-32 at 32 drones per
+ * workgroup: 48 of 428 words); ld_fly_steps_kept_words_f32 reports the split.  Results are bit-identical to n_steps
  * calls of ld_fly_step_f32 for every waves_per_block, with and without the kept genes.  ld_fly_step_f32 itself is
  * ld_fly_steps_f32(..., 1, 0, stream) for those specs. */
 int ld_fly_steps_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
@@ -330,11 +335,11 @@ int ld_fly_rollout_geometry_f32(const ld_mlp_spec *spec, int64_t n, int32_t time
                                 int32_t *steps_per_launch, int32_t *waves_per_block, int32_t *n_launches,
                                 int64_t *tile_drones);
 /* Accounting: gene words per drone (16 bytes each) that a launch of ld_fly_steps_f32(..., n_steps, waves_per_block)
- * keeps in LDS for the whole launch and gene words per drone it streams from memory EVERY timestep (0 and
- * ld_mlp_words_per_drone when the launch keeps nothing; a word that straddles two wavefronts' rows is loaded by
- * both, so the two can add up to a little more than that). */
+ * keeps in LDS for the whole launch, holds in registers for the whole launch, and loads from memory EVERY timestep
+ * (0, 0 and ld_mlp_words_per_drone when the launch keeps nothing; a word that straddles two wavefronts' rows is loaded
+ * by both, so the three can add up to a little more than that). */
 int ld_fly_steps_kept_words_f32(const ld_mlp_spec *spec, int32_t waves_per_block, int32_t n_steps,
-                                int64_t *kept_words, int64_t *streamed_words);
+                                int64_t *lds_words, int64_t *register_words, int64_t *streamed_words);
 
 /* The wavefronts per genome block ld_fly_steps_f32 takes for waves_per_block = 0 on a launch of n drones and
  * n_steps timesteps (1 for specs without an unrolled specialisation), or a negative ld_status. */

@@ -108,7 +108,7 @@ def _declare(h: C.CDLL) -> None:
     h.ld_has_resident_f32.argtypes = [spec]
     h.ld_has_resident_f64.argtypes = [spec]
     h.ld_fly_steps_auto_waves_f32.argtypes = [spec, i64, i32]
-    h.ld_fly_steps_kept_words_f32.argtypes = [spec, i32, i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    h.ld_fly_steps_kept_words_f32.argtypes = [spec, i32, i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     h.ld_accelerations_frames_f32.argtypes = [sim, vp, vp, vp, vp, vp, i32, i64, vp]
     h.ld_accelerations_frames_f64.argtypes = [sim, vp, vp, vp, vp, vp, i32, i64, vp]
     h.ld_fly_steps_resident_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, i64, i32, vp, vp]

@@ -42,9 +42,7 @@ std::atomic<int> g_lds_keep{-1};              // ld_debug_lds_keep: -1 = the lib
 #ifndef LD_KEEP_MIN_STEPS
 #define LD_KEEP_MIN_STEPS 8
 #endif
-#ifndef LD_KEEP_KIB
-#define LD_KEEP_KIB 136                        // = LD_SPLIT_KEEP_KIB of ld_split.inc
-#endif
+
 int keep_bit(int32_t n_steps)
 {
     const int mode = g_lds_keep.load(std::memory_order_relaxed);
@@ -180,10 +178,10 @@ bool keeps_genes(const ld_mlp_spec* spec, int32_t n_steps)
 }
 
 // What KeepPlan<8, ...> (ld_split.hpp) works out at compile time, at run time, for the accounting entry point
-// ld_fly_steps_kept_words_f32: gene words per drone a launch keeps in LDS and gene words per drone it streams every
+// ld_fly_steps_kept_words_f32: gene words per drone a launch keeps in LDS, holds in registers, and loads from memory every
 // timestep, for workgroups of 8 wavefronts flying `lanes` drones each.  (A word that straddles two wavefronts' rows is
-// loaded by both: the two numbers add up to a little more than ld_mlp_words_per_drone.)
-void keep_plan(const ld_mlp_spec& spec, int lanes, int64_t* kept, int64_t* streamed)
+// loaded by both: the three numbers add up to a little more than ld_mlp_words_per_drone.)
+void keep_plan(const ld_mlp_spec& spec, int lanes, int64_t* in_lds, int64_t* in_registers, int64_t* streamed)
 {
     constexpr int L = 8;
     int dims[LD_MAX_HIDDEN_LAYERS + 2];
@@ -202,13 +200,16 @@ void keep_plan(const ld_mlp_spec& spec, int lanes, int64_t* kept, int64_t* strea
         }
         total += len[k];
     }
-    const int64_t keep_words = (int64_t)LD_KEEP_KIB * 1024 / (lanes * 16);
-    *kept = 0;
+    const int64_t keep_words = (int64_t)LD_SPLIT_KEEP_KIB * 1024 / (lanes * 16);
+    const int64_t reg_words = lanes == 64 ? LD_SPLIT_REG_WORDS_64 : lanes == 48 ? LD_SPLIT_REG_WORDS_48 : lanes == 32 ? LD_SPLIT_REG_WORDS_32 : 0;
+    *in_lds = *in_registers = 0;
     for (int k = 0; k < L; ++k) {
-        const int64_t want = len[k] * keep_words / total;
-        *kept += want < len[k] ? want : len[k];
+        const int64_t want = len[k] * keep_words / total, lds = want < len[k] ? want : len[k];
+        const int64_t rest = len[k] - lds, regs = reg_words < rest ? reg_words : rest;
+        *in_lds += lds;
+        *in_registers += regs;
     }
-    *streamed = total - *kept;
+    *streamed = total - *in_lds - *in_registers;
 }
 
 int auto_waves_per_block(const ld_mlp_spec* spec, int64_t n, int32_t n_steps)
@@ -741,17 +742,18 @@ int ld_fly_rollout_geometry_f32(const ld_mlp_spec* spec, int64_t n, int32_t time
     return LD_OK;
 }
 
-int ld_fly_steps_kept_words_f32(const ld_mlp_spec* spec, int32_t waves_per_block, int32_t n_steps, int64_t* kept_words,
-                                int64_t* streamed_words)
+int ld_fly_steps_kept_words_f32(const ld_mlp_spec* spec, int32_t waves_per_block, int32_t n_steps, int64_t* lds_words,
+                                int64_t* register_words, int64_t* streamed_words)
 {
     const int rc = check_spec(spec);
     if (rc) return rc;
     if (!valid_waves(waves_per_block) || n_steps < 0) return LD_ERR_SIZE;
-    if (!kept_words || !streamed_words) return LD_ERR_NULL;
-    *kept_words = 0;
+    if (!lds_words || !register_words || !streamed_words) return LD_ERR_NULL;
+    *lds_words = *register_words = 0;
     *streamed_words = ld_mlp_words_per_drone(spec);
     const int lanes = waves_per_block == 8 ? 64 : waves_per_block == 11 ? 48 : waves_per_block == 16 ? 32 : waves_per_block == 32 ? 16 : 0;
-    if (lanes && has_unrolled(*spec) && ld_mlp_words_per_drone(spec) <= 512 && keep_bit(n_steps)) keep_plan(*spec, lanes, kept_words, streamed_words);
+    if (lanes && has_unrolled(*spec) && ld_mlp_words_per_drone(spec) <= 512 && keep_bit(n_steps))
+        keep_plan(*spec, lanes, lds_words, register_words, streamed_words);
     return LD_OK;
 }
 

@@ -23,6 +23,23 @@
 
 #include "ld_kernels.hpp"
 
+// KiB of LDS a workgroup of the keeping variants fills with gene words (of the CU's 160: the exchange rows and the
+// tables take up to 19)
+#ifndef LD_SPLIT_KEEP_KIB
+#define LD_SPLIT_KEEP_KIB 136
+#endif
+// ... and gene words per WAVEFRONT they hold in registers for the whole launch on top (workgroups of 64 / 48 / 32 drones; the
+// workgroups of 16 keep everything in LDS).  32-32, us per timestep of 65 536 drones at 0 / 8 / 12 (14) words: workgroups of 64
+// 41.3 / 32.1 / 27.5, of 48 36.2 / 30.1 / 27.8, of 32 29.3 / 25.0 / 23.3 (scripts/exp_lds_keep4.py with variant builds).
+#ifndef LD_SPLIT_REG_WORDS_64
+#define LD_SPLIT_REG_WORDS_64 12
+#endif
+#ifndef LD_SPLIT_REG_WORDS_48
+#define LD_SPLIT_REG_WORDS_48 12
+#endif
+#ifndef LD_SPLIT_REG_WORDS_32
+#define LD_SPLIT_REG_WORDS_32 14
+#endif
 // kept gene words in flight from LDS per lane (4: the all-in-LDS launches 3.32 -> 3.15 us per timestep against 2)
 #ifndef LD_SPLIT_KEEP_DEPTH
 #define LD_SPLIT_KEEP_DEPTH 4
@@ -84,47 +101,71 @@ template <int L, int... H> struct SplitPlan {
 // so the ring of streamed words advances at an even, lower rate.  A kept word is read back by the lane that wrote
 // it (ds_read_b128 of 64 consecutive 16-byte slots: conflict-free), so no barrier is involved, and every neuron's
 // sum still runs over the same genes in the same order: results are bit-identical to KeepWords = 0.
-template <int L, int KeepWords, int... H> struct KeepPlan {
+// RegWords > 0: each wavefront also holds that many of its not-LDS-kept words in REGISTERS for the whole launch (the
+// registers a shallower ring leaves free), again spread evenly over its stream.
+//
+// The plan is worked out ONCE per instantiation into tables (the kernel asks for it word by word; the front end would
+// otherwise re-walk a wavefront's stream for every word, minutes of compile time per kernel): the class of every stream
+// position -- 0 = kept in LDS, 1 = held in a register, 2 = loaded every timestep --, its index within its class, and the
+// position of the j-th word of each class.
+template <int L, int KeepWords, int RegWords, int... H> struct KeepPlan {
     using Plan = SplitPlan<L, H...>;
-    static constexpr int total()
+    static constexpr int N = Plan::max_stream_len() > 0 ? Plan::max_stream_len() : 1;
+    struct Tables {
+        int len[L];                 // stream length of wavefront k
+        int n[3][L];                // words of each class
+        int cls[L][N], idx[L][N];   // class of position s, and its index within the class
+        int pos[3][L][N];           // position of the j-th word of a class
+        int lds_base[L + 1];        // first LDS row of wavefront k
+    };
+    static constexpr Tables build()
     {
-        int t = 0;
-        for (int k = 0; k < L; ++k) t += Plan::stream_len(k);
+        Tables t{};
+        int total = 0;
+        for (int k = 0; k < L; ++k) { t.len[k] = Plan::stream_len(k); total += t.len[k]; }
+        t.lds_base[0] = 0;
+        for (int k = 0; k < L; ++k) {
+            const int len = t.len[k];
+            int keep = KeepWords == 0 || total == 0 ? 0 : (int)((long long)len * KeepWords / total);
+            keep = keep < len ? keep : len;
+            const int rest = len - keep;
+            const int regs = RegWords < rest ? RegWords : rest;
+            t.n[0][k] = keep; t.n[1][k] = regs; t.n[2][k] = rest - regs;
+            t.lds_base[k + 1] = t.lds_base[k] + keep;
+            int seen[3] = {0, 0, 0};
+            int q = 0;                                          // index among the words not kept in LDS
+            for (int s = 0; s < len; ++s) {
+                // position s is kept when floor((s+1) keep / len) > floor(s keep / len); of the others, the q-th is
+                // register-held when floor((q+1) regs / rest) > floor(q regs / rest)
+                int c = 2;
+                if (keep > 0 && (long long)(s + 1) * keep / len != (long long)s * keep / len) c = 0;
+                else {
+                    if (regs > 0 && (long long)(q + 1) * regs / rest != (long long)q * regs / rest) c = 1;
+                    ++q;
+                }
+                t.cls[k][s] = c; t.idx[k][s] = seen[c]; t.pos[c][k][seen[c]] = s;
+                ++seen[c];
+            }
+        }
         return t;
     }
-    static constexpr int count(int k)                           // kept words of wavefront k
-    {
-        const int want = (int)((long long)Plan::stream_len(k) * KeepWords / total());
-        return want < Plan::stream_len(k) ? want : Plan::stream_len(k);
-    }
-    static constexpr int base(int k)                            // first LDS row of wavefront k
-    {
-        int b = 0;
-        for (int j = 0; j < k; ++j) b += count(j);
-        return b;
-    }
-    static constexpr int rows = base(L) + LD_SPLIT_KEEP_DEPTH;  // (the top-of-step reads of a wavefront with fewer kept words than it keeps in flight)
-    static constexpr int kept_before(int k, int s) { return (int)((long long)s * count(k) / Plan::stream_len(k)); }
-    static constexpr bool kept(int k, int s) { return count(k) > 0 && kept_before(k, s + 1) != kept_before(k, s); }
-    static constexpr int streamed_before(int k, int s) { return s - kept_before(k, s); }
-    static constexpr int streamed_len(int k) { return Plan::stream_len(k) - count(k); }
-    static constexpr int max_streamed_len()
+    static constexpr Tables T = build();
+
+    static constexpr int count(int k) { return T.n[0][k]; }                     // words kept in LDS
+    static constexpr int reg_count(int k) { return T.n[1][k]; }                 // words held in registers
+    static constexpr int loaded_len(int k) { return T.n[2][k]; }                // words loaded every timestep
+    static constexpr int base(int k) { return T.lds_base[k]; }                  // first LDS row of wavefront k
+    static constexpr int rows = T.lds_base[L] + LD_SPLIT_KEEP_DEPTH;            // (+ the top-of-step reads of a wavefront with fewer kept words than it keeps in flight)
+    static constexpr int cls(int k, int s) { return T.cls[k][s]; }
+    static constexpr int idx(int k, int s) { return T.idx[k][s]; }
+    static constexpr int pos_of_kept(int k, int j) { return T.pos[0][k][j]; }
+    static constexpr int pos_of_reg(int k, int j) { return T.pos[1][k][j]; }
+    static constexpr int pos_of_loaded(int k, int j) { return T.pos[2][k][j]; }
+    static constexpr int max_loaded_len()
     {
         int m = 0;
-        for (int k = 0; k < L; ++k) m = streamed_len(k) > m ? streamed_len(k) : m;
+        for (int k = 0; k < L; ++k) m = T.n[2][k] > m ? T.n[2][k] : m;
         return m;
-    }
-    static constexpr int pos_of_streamed(int k, int q)          // stream position of the q-th streamed word
-    {
-        for (int s = 0; s < Plan::stream_len(k); ++s)
-            if (!kept(k, s) && streamed_before(k, s) == q) return s;
-        return 0;
-    }
-    static constexpr int pos_of_kept(int k, int j)              // stream position of the j-th kept word
-    {
-        for (int s = 0; s < Plan::stream_len(k); ++s)
-            if (kept(k, s) && kept_before(k, s) == j) return s;
-        return 0;
     }
 };
 
@@ -194,13 +235,13 @@ extern __device__ unsigned long long ld_diag_cycles[8][8];
 #ifndef LD_SPLIT_HEAD_L8
 #define LD_SPLIT_HEAD_L8 8
 #endif
-// ... and of the kernels that keep genes in LDS: 8 words.  Measured (scripts/exp_lds_keep4.py, 32-32, us per timestep at a
-// ring of 16 / 12 / 8 / 4 words): 8 192 drones in workgroups of 32: 5.49 / 5.45 / 3.82 / 4.53; 65 536 in one launch: 43.3 /
-// 42.9 / 29.9 / 35.8; workgroups of 64 and of 48 drones do not care (9.3 and 6.0-6.1 throughout).  With 64 % of the genes in
-// LDS the streamed rest of the resident workgroups' genes (20 MB chip-wide) is about what the L2s hold, and the shallower
-// ring leaves it there.
+// ... and of the kernels that keep genes in LDS and in registers: 4 words.  Measured (scripts/exp_lds_keep4.py, 32-32, us per
+// timestep of 65 536 drones in one launch, two workgroups per block): ring of 16 / 12 / 8 / 4 words, nothing held in
+// registers: 43.3 / 42.9 / 29.9 / 35.8 -- with 64 % of the genes in LDS the streamed rest of the resident workgroups' genes
+// (20 MB chip-wide) is about what the L2s hold, and a shallower ring leaves it there; the registers the ring gives up hold
+// gene words instead (KeepPlan, RegWords): ring of 8 with 12 words per wavefront held 24.3, ring of 4 with 14 held 23.3.
 #ifndef LD_SPLIT_DEPTH_CAP_KEEP
-#define LD_SPLIT_DEPTH_CAP_KEEP 8
+#define LD_SPLIT_DEPTH_CAP_KEEP 4
 #endif
 
 // S > 1: a 64-drone genome block is served by S workgroups of L wavefronts, each flying 64 / S of its drones on
@@ -209,7 +250,7 @@ extern __device__ unsigned long long ld_diag_cycles[8][8];
 // at the most one CU can draw from L2 / Infinity Cache (~50 GB/s); two workgroups per block use every CU.
 // The genes are loaded with the non-temporal hint (ld_device.hpp, LD_GENE_NT).
 // KeepKiB > 0: that many KiB of the workgroup's LDS hold gene words for the whole launch (KeepPlan above).
-template <typename Real, bool Faithful, int L, int S, int KeepKiB, int... H>
+template <typename Real, bool Faithful, int L, int S, int KeepKiB, int RegWords, int... H>
 __global__ void __launch_bounds__(64 * L)
 fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restrict__ coins,
                  const double* __restrict__ walls, const GeneWord<Real>* __restrict__ genomes,
@@ -232,9 +273,9 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
     // straddle the 64-drone genome blocks: a gene word is then 768 bytes in two pieces of whole 128-byte lines)
     constexpr int kLanes = S == 3 ? 48 : 64 / S;
     constexpr int kKeepWords = KeepKiB * 1024 / (kLanes * (int)sizeof(GeneWord<Real>));
-    using Keep = KeepPlan<L, kKeepWords, H...>;
+    using Keep = KeepPlan<L, kKeepWords, RegWords, H...>;
     constexpr bool kKeeps = kKeepWords > 0;
-    constexpr int kStreamMax = Keep::max_streamed_len() > 0 ? Keep::max_streamed_len() : 1;
+    constexpr int kStreamMax = Keep::max_loaded_len() > 0 ? Keep::max_loaded_len() : 1;
     constexpr int D = kWant < kStreamMax ? kWant : kStreamMax;
     constexpr int KD = LD_SPLIT_KEEP_DEPTH;                   // kept words in flight from LDS per lane
 
@@ -270,10 +311,11 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
         constexpr int B = decltype(part)::value == 0 ? kHead : D;
         LD_PREFETCH_DISPATCH<L>(wave, [&](auto kc) __attribute__((always_inline)) {
             constexpr int K = decltype(kc)::value;
-            constexpr int N = Keep::streamed_len(K);
+            constexpr int N = Keep::loaded_len(K);
             static_for<A, (B < N ? B : N)>([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value;
-                ring[q] = load_word<Real>(genomes, lane_offset, Plan::word_at(K, Keep::pos_of_streamed(K, q)));
+                constexpr int word = Plan::word_at(K, Keep::pos_of_loaded(K, q));      // (constexpr locals: evaluated by the front end,
+                ring[q] = load_word<Real>(genomes, lane_offset, word);                 // never left to the optimiser as run-time searches)
             });
         });
     };
@@ -290,7 +332,8 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
                 constexpr int c0 = decltype(cc)::value * D, c1 = c0 + D < R ? c0 + D : R;
                 static_for<c0, c1>([&](auto jc) __attribute__((always_inline)) {
                     constexpr int j = decltype(jc)::value;
-                    ring[j - c0] = load_word<Real>(genomes, lane_offset, Plan::word_at(K, Keep::pos_of_kept(K, j)));
+                    constexpr int word = Plan::word_at(K, Keep::pos_of_kept(K, j));
+                    ring[j - c0] = load_word<Real>(genomes, lane_offset, word);
                 });
                 static_for<c0, c1>([&](auto jc) __attribute__((always_inline)) {
                     constexpr int j = decltype(jc)::value;
@@ -300,6 +343,23 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
         });
     }
     GeneWord<Real> kring[KD];
+    // ---- the register-held words: loaded once, live for the whole launch
+    GeneWord<Real> rkept[RegWords > 0 ? RegWords : 1];
+    if constexpr (RegWords > 0) {
+        LD_PREFETCH_DISPATCH<L>(wave, [&](auto kc) __attribute__((always_inline)) {
+            constexpr int K = decltype(kc)::value;
+            static_for<0, Keep::reg_count(K)>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int word = Plan::word_at(K, Keep::pos_of_reg(K, i));
+                rkept[i] = load_word<Real>(genomes, lane_offset, word);
+            });
+        });
+        // opaque from here on: a plain load of read-only memory is loop-invariant, and the compiler would rather load
+        // it again inside the timestep loop than hold four registers for it
+#pragma unroll
+        for (int i = 0; i < RegWords; ++i)
+            asm volatile("" : "+v"(rkept[i].g[0]), "+v"(rkept[i].g[1]), "+v"(rkept[i].g[2]), "+v"(rkept[i].g[3]));
+    }
     // One prefetch site only (at the top of the loop body): with a second one behind the last layer the
     // register allocator keeps two copies of the ring.
     bool dead0 = false, dead = false;
@@ -384,9 +444,10 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
                         // the software pipeline of UnrolledNet::forward (ld_nets.hpp): nothing moves across the
                         // sched_barrier, and the refill's address depends on this word's result
                         __builtin_amdgcn_sched_barrier(0);
-                        constexpr bool from_lds = Keep::kept(K, s);
-                        constexpr int kj = Keep::kept_before(K, s), sq = Keep::streamed_before(K, s);
-                        const GeneWord<Real> v = from_lds ? kring[kj % KD] : ring[sq % D];
+                        constexpr bool from_lds = Keep::cls(K, s) == 0, from_reg = Keep::cls(K, s) == 1;
+                        constexpr int kj = from_lds ? Keep::idx(K, s) : 0, ri = from_reg ? Keep::idx(K, s) : 0;
+                        constexpr int sq = from_lds || from_reg ? 0 : Keep::idx(K, s);
+                        const GeneWord<Real> v = from_lds ? kring[kj % KD] : (from_reg ? rkept[ri] : ring[sq % D]);
                         static_for<0, 4>([&](auto cc) __attribute__((always_inline)) {
                             constexpr int cidx = decltype(cc)::value;
                             constexpr int p = 4 * w + cidx;
@@ -405,10 +466,10 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
                         });
                         if constexpr (from_lds) {
                             if constexpr (kj + KD < Keep::count(K)) kring[kj % KD] = my_kept[(kj + KD) * kLanes];
-                        } else if constexpr (sq + D < Keep::streamed_len(K)) {
+                        } else if constexpr (!from_reg && sq + D < Keep::loaded_len(K)) {
                             asm volatile("" : "+v"(lane_offset) : "v"(acc));
-                            ring[sq % D] = load_word<Real>(genomes, lane_offset,
-                                                                     Plan::word_at(K, Keep::pos_of_streamed(K, sq + D)));
+                            constexpr int word = Plan::word_at(K, Keep::pos_of_loaded(K, sq + D));
+                            ring[sq % D] = load_word<Real>(genomes, lane_offset, word);
                         }
                     });
                     if constexpr (L == 1) {
@@ -454,13 +515,13 @@ fly_split_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __restr
     }
 }
 
-template <typename Real, bool Faithful, int L, int S, int KeepKiB, int... H>
+template <typename Real, bool Faithful, int L, int S, int KeepKiB, int RegWords, int... H>
 int launch_fly_split(const ld_sim_params* sim, const ld_episode_params* ep, const double* coins, const double* walls,
                      const Real* genomes, Real* fstate, int32_t* istate, int64_t n, int64_t begin, int64_t end,
                      int32_t n_steps, hipStream_t stream)
 {
     static_assert(S == 1 || S == 2 || S == 3 || S == 4, "workgroups of 64, 32, 48 or 16 drones");
-    hipLaunchKernelGGL((fly_split_kernel<Real, Faithful, L, S, KeepKiB, H...>), dim3(blocks_for(end - begin, S == 3 ? 48 : 64 / S)), dim3(64 * L), 0, stream,
+    hipLaunchKernelGGL((fly_split_kernel<Real, Faithful, L, S, KeepKiB, RegWords, H...>), dim3(blocks_for(end - begin, S == 3 ? 48 : 64 / S)), dim3(64 * L), 0, stream,
                        make_sim<Real>(*sim), make_ep<Real>(*ep), coins, walls,
                        reinterpret_cast<const GeneWord<Real>*>(genomes), fstate, istate, n, begin, end, n_steps);
     return check_launch("fly_split_kernel");

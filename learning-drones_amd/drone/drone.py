@@ -81,9 +81,9 @@ class Drone(ControlUnit):
             s.previous_vel = float(row22[3 + i]) if i < 3 else float(row22[6 + i])
         self.thrust = _column(row22[18:22], 4)
 
-    def _population(self):
-        from ..scalar import scalar_population
-        return scalar_population(controller_spec(self.controller), self.precision)
+    def _engine(self):
+        from ..scalar import scalar_engine
+        return scalar_engine(controller_spec(self.controller), self.precision)
 
     # ---- reference methods
     def enable_visualization(self, visualize, n_servers, port, dir_name="./rewatch"):
@@ -94,17 +94,17 @@ class Drone(ControlUnit):
             self.position, self.velocity, self.angle, self.angle_vel, np.asarray(coin_position, float).reshape(3, 1))
 
     def measure(self, wind_speed):
-        """One physics + integration step with crash / instability reward (drone.py:129-165)."""
-        pop = self._population()
-        pop.sim = self.quadcopter.sim_params(wind_speed)
-        pop.episode = EpisodeParams.reference(n_coins=pop.episode.n_coins, coin_respawn=bool(pop.episode.coin_respawn))
-        pop.reset()
-        pop.set_state(self._state12()[None], self._acc6()[None], self.thrust.reshape(1, 4))
-        pop.measure()
-        row = pop.state_numpy()[0]
+        """One physics + integration step with crash / instability reward (drone.py:129-165): one launch of ld_measure_*
+        on the resident 1-drone engine (scalar.py: pinned staging, one synchronisation per call)."""
+        eng = self._engine()
+        key = tuple(float(w) for w in np.asarray(wind_speed, dtype=float).ravel())
+        if getattr(self, "_sim_key", None) != key:                      # the uniform block only changes with the wind
+            self._sim, self._sim_key = self.quadcopter.sim_params(wind_speed), key
+            self._episode = EpisodeParams.reference(n_coins=1)
+        row, reward, crashed = eng.measure(self._sim, self._episode, self._state12(), self._acc6(), self.thrust.ravel())
         self._store(row)
-        self.reward += int(pop.reward.item())
-        if bool(pop.crashed.item()):
+        self.reward += reward
+        if crashed:
             self.crashed = True
             return True
         return False

@@ -6,7 +6,7 @@ import numpy as np
 import numpy.random as npr
 
 from ..drone.onboard_computer import ControlUnit
-from ..params import MlpSpec, flatten_weights
+from ..params import MlpSpec
 
 
 class NeuralNetwork(ControlUnit):
@@ -43,10 +43,8 @@ class NeuralNetwork(ControlUnit):
         x = np.asarray(input_vec, dtype=np.float64)
         if x.ndim != 2 or x.shape[1] != 1:
             raise AssertionError(x.shape)                    # brain.py:48 column-vector assert
-        from ..scalar import scalar_population
-        pop = scalar_population(self.spec, self.precision)
-        pop.set_genomes(flatten_weights(self.weights)[None, :])
-        return pop.feed_forward(x).double().cpu().numpy().reshape(-1, 1)
+        from ..scalar import scalar_engine
+        return scalar_engine(self.spec, self.precision).feed_forward(self.weights, x.ravel()).reshape(-1, 1)
 
     def translate_input_to_thrust(self, drone_position, drone_velocity, drone_angle, drone_angle_velocity,
                                   coin_position):

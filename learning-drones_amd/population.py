@@ -347,20 +347,20 @@ class Population:
                       "ld_fly_rollout_geometry_f32")
         if self.precision == "f64":             # the same timesteps per launch, one wavefront per block, no tiles
             return {"steps_per_launch": k.value, "waves_per_block": 1, "launches": -(-int(timesteps) // k.value), "tile_drones": self.n,
-                    "kept_words": 0, "streamed_words": self.W}
-        kept, streamed = self.kept_words(w.value, min(k.value, int(timesteps)))
+                    "lds_words": 0, "register_words": 0, "streamed_words": self.W}
+        lds, regs, streamed = self.kept_words(w.value, min(k.value, int(timesteps)))
         return {"steps_per_launch": k.value, "waves_per_block": w.value, "launches": m.value, "tile_drones": tile.value,
-                "kept_words": kept, "streamed_words": streamed}
+                "lds_words": lds, "register_words": regs, "streamed_words": streamed}
 
     def kept_words(self, waves_per_block: int, n_steps: int):
-        """(gene words per drone a launch keeps in LDS, gene words per drone it streams every timestep) for a launch
-        of `n_steps` timesteps in the geometry `waves_per_block` (ld_fly_steps_kept_words_f32)."""
+        """Gene words per drone a launch of `n_steps` timesteps in the geometry `waves_per_block` (keeps in LDS, holds in
+        registers, loads from memory every timestep) (ld_fly_steps_kept_words_f32)."""
         if self.precision != "f32":
-            return 0, self.W
-        kept, streamed = C.c_int64(0), C.c_int64(0)
-        _native.check(_native.lib().ld_fly_steps_kept_words_f32(C.byref(self.spec), int(waves_per_block), int(n_steps),
-                                                                C.byref(kept), C.byref(streamed)), "ld_fly_steps_kept_words_f32")
-        return kept.value, streamed.value
+            return 0, 0, self.W
+        lds, regs, streamed = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _native.check(_native.lib().ld_fly_steps_kept_words_f32(C.byref(self.spec), int(waves_per_block), int(n_steps), C.byref(lds),
+                                                                C.byref(regs), C.byref(streamed)), "ld_fly_steps_kept_words_f32")
+        return lds.value, regs.value, streamed.value
 
     def auto_waves_per_block(self, drones: int, steps_per_launch: int) -> int:
         """Wavefronts per genome block the library chooses (waves_per_block = 0) for a launch of `drones` drones

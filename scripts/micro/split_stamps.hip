@@ -41,7 +41,7 @@ int run(int64_t n, int steps, int reps)
         CHECK(hipMemcpyToSymbol(HIP_SYMBOL(ld::ld_diag_cycles), zero, sizeof zero));
         if (ld_population_reset_f32(fstate, istate, n, nullptr, nullptr)) return 1;
         CHECK(hipEventRecord(e0, nullptr));
-        if (ld::launch_fly_split<float, false, 8, S, true, Keep, 32, 32>(&sim, &ep, coins, nullptr, genomes, fstate, istate, n, 0, n, steps, nullptr)) return 1;
+        if (ld::launch_fly_split<float, false, 8, S, Keep, 0, 32, 32>(&sim, &ep, coins, nullptr, genomes, fstate, istate, n, 0, n, steps, nullptr)) return 1;
         CHECK(hipEventRecord(e1, nullptr));
         CHECK(hipDeviceSynchronize());
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));

@@ -4,6 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 out=$PWD/gpurun_out/prof
+rm -rf $out          # (rocprofv3 adds a directory per run: old runs would be averaged in)
 mkdir -p $out
 export TMPDIR=/tmp
 # page the image in and bring the GPU to its sustained clocks before anything is recorded (the first run on a fresh box is ~5 % slow)
@@ -24,4 +25,7 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/c3_cl
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/full_trace -- python3 bench.py --no-cpu-baseline > $out/full_trace.json 2> $out/full_trace.err
 find $out/full_trace -name '*kernel_trace.csv' -delete
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --output-format csv -d $out/full_sq -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/full_sq.json 2> $out/full_sq.err
+# memory-side traffic of the generation step's kernels (ga_breed_kernel gathers 16-byte parent words: how many bytes do the L2s fetch for them?)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/full_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/full_fetch.json 2> $out/full_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/full_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/full_write.json 2> $out/full_write.err
 echo "all profiled"; du -sh $out

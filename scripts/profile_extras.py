@@ -58,6 +58,26 @@ json.dump({"round": ROUND, "command": "rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ
            "note": "per-dispatch means over the dispatches within 20 % of the kernel's largest SQ_WAVE_CYCLES (full live-population launches: the bench also flies random-genome populations whose launches are mostly frozen); SQ_* cycle counters are quad-cycles summed over waves (MI355X_MICROARCH.md); fly_split L = wavefronts per workgroup, S = workgroups per 64-drone block (3: workgroups of 48 drones), keep = KiB of genes per workgroup kept in LDS; fly_resident: a whole 2 000-step episode of 65 536 drones per launch",
            "kernels": out}, open(f"profiles/{R}_sq_counters.json", "w"), indent=1)
 
+# ---- memory-side traffic of the generation step's breed kernel
+breed = {}
+for name, d in (("FETCH_SIZE", "full_fetch"), ("WRITE_SIZE", "full_write")):
+    vals = [float(r["Counter_Value"]) for r in load(f"{P}/{d}/**/*counter_collection.csv") if "ga_breed_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name]
+    if vals:
+        breed[name + "_mean_kb"] = statistics.fmean(vals)
+        breed["dispatches"] = len(vals)
+if breed:
+    bench = last_json(f"{P}/full_trace.json")
+    P4 = 4 * sum(a * b for a, b in zip([32, 32, 4], [16, 33, 33]))            # config 3: 4P bytes per drone
+    n = bench["config"]["population"] // bench["n_gpus"]
+    breed.update(algorithmic_bytes=2 * P4 * n, read_bytes=2 * breed.get("FETCH_SIZE_mean_kb", 0) * 1024, write_bytes=breed.get("WRITE_SIZE_mean_kb", 0) * 1024,
+                 select_breed_ms=bench["generation"]["select_breed_ms"],
+                 note="ga_breed_kernel at config 3: every lane reads one 16-byte word of ITS child's parent, 64 different parents per wavefront: "
+                      "64 sectors of 128 bytes for 1 KiB of genes; read_bytes = 2 x FETCH_SIZE (gfx950 correction) is what the L2s fetched for it")
+    breed["read_over_algorithmic_read"] = breed["read_bytes"] / (P4 * n)
+    json.dump({"round": ROUND, "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
+               "ga_breed_kernel": breed}, open(f"profiles/{R}_ga_breed_pmc.json", "w"), indent=1)
+    print("ga_breed_kernel", breed)
+
 # ---- kernel stats
 def stats(src_glob, dst, top):
     rows = load(src_glob)

@@ -247,7 +247,7 @@ def _replicated(hidden, m, n, seed):
 def test_full_size_config4_shard(Population, torch):
     """One GPU's share of BASELINE config 4: 32 768 drones x 4 000 steps, 15-32-32-4, 3-coin chain (the
     launch geometry this shard gets: 64 timesteps per launch, all 32 768 drones in one launch, two workgroups of 8 wavefronts per
-    genome block, each keeping 136 KiB = 268 of its 32 drones' 428 streamed gene words in LDS for the launch).  Size-independent
+    genome block, each keeping 268 of its 32 drones' 428 gene words in LDS and 112 in registers for the launch).  Size-independent
     properties: genomes replicated from a 256-drone population under a random permutation give the
     permuted small-population results bit for bit; a re-run is bit-identical; one launch per timestep
     and the resident engine give the same records."""
@@ -261,7 +261,7 @@ def test_full_size_config4_shard(Population, torch):
     pop = Population(n, hidden, coins=coins)
     pop.set_genomes(torch.as_tensor(genes_m, dtype=torch.float32, device="cuda")[torch.as_tensor(src, device="cuda")])
     geo = pop.rollout_geometry(T)
-    assert geo == {"steps_per_launch": 64, "waves_per_block": 16, "launches": 63, "tile_drones": 32768, "kept_words": 268, "streamed_words": 160}
+    assert geo == {"steps_per_launch": 64, "waves_per_block": 16, "launches": 63, "tile_drones": 32768, "lds_words": 268, "register_words": 112, "streamed_words": 48}
     pop.fly(T)
     got = pop.results()
     for f in ("reward", "flight_time", "coins", "crashed", "distance_to_coin"):
@@ -594,7 +594,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     top = max(r["levels"].values(), key=lambda v: v["frac"])
     assert r["frac"] == top["frac"] and r["achieved"] == top["achieved"] and r["peak"] == top["peak"] and 0 < r["frac"] <= 1.0
     assert r["levels"]["hbm"]["peak"] == 8000.0 and r["unit"] in ("GB/s", "G wave-instructions/s")
-    assert r["launch_us"] > 0 and "traffic" in r and r["kept_words_per_drone"] == 428 and r["streamed_words_per_drone"] == 0   # 4 096 drones: 16 per workgroup
+    assert r["launch_us"] > 0 and "traffic" in r and r["lds_words_per_drone"] == 428 and r["streamed_words_per_drone"] == 0   # 4 096 drones: 16 per workgroup
     assert "roofline_hbm_bound" in d and d["one_timestep_per_launch"]["bound"] == "hbm"
     assert "exchange_bytes_per_generation_per_rank" in d["generation"]
     c = d["cpu_baseline"]
@@ -641,10 +641,10 @@ def test_kept_genes_are_bit_identical_on_a_ragged_population(Population, torch, 
     pop = Population(n, hidden, walls=walls, coins=coin_chain_reference(2))
     pop.set_genomes(torch.as_tensor(genes_m, dtype=torch.float32, device="cuda")[torch.as_tensor(src, device="cuda")])
     geo = pop.rollout_geometry(T)
-    assert geo["tile_drones"] == n and geo["waves_per_block"] == 16 and geo["kept_words"] == 268
+    assert geo["tile_drones"] == n and geo["waves_per_block"] == 16 and geo["lds_words"] == 268 and geo["register_words"] == 112
     assert lib.ld_debug_lds_keep(0) == -1
     try:
-        assert pop.rollout_geometry(T)["tile_drones"] == 16384 and pop.rollout_geometry(T)["kept_words"] == 0
+        assert pop.rollout_geometry(T)["tile_drones"] == 16384 and pop.rollout_geometry(T)["lds_words"] == 0
         pop.fly(T)                                                        # nothing kept: tiles, four wavefronts per block
     finally:
         assert lib.ld_debug_lds_keep(-1) == 0
@@ -719,7 +719,7 @@ def test_rollout_is_capturable_in_a_hip_graph(Population, torch):
     n, T = 16384, 200
     pop = Population(n, (32, 32), coins=coin_chain_reference(3))
     pop.set_genomes(make_genomes(torch, n, (32, 32), pop.device, 0))
-    assert pop.rollout_geometry(T)["kept_words"] > 0                      # the captured launches keep genes in LDS
+    assert pop.rollout_geometry(T)["lds_words"] > 0                       # the captured launches keep genes in LDS
     pop.fly(T)
     want = pop.records.clone()
     pop.reset()

@@ -187,17 +187,19 @@ def test_argument_validation_without_gpu(lib):
     assert geo((32, 32), 32768, 4000) == (OK, 64, 16, 63, 32768)          # config 4 shard
     assert geo((32, 32), 16384, 2000) == (OK, 64, 16, 32, 16384) and geo((32, 32), 1024, 2000) == (OK, 64, 32, 32, 1024)
     assert geo((16, 16), 65536, 2000) == (OK, 64, 8, 32, 65536) and geo((16, 16), 1024, 2000) == (OK, 64, 32, 32, 1024)   # config 2
-    kept, streamed = C.c_int64(), C.c_int64()
-    words = lambda h, w, steps: (lib.ld_fly_steps_kept_words_f32(C.byref(MlpSpec.from_hidden(h)), w, steps, C.byref(kept), C.byref(streamed)),
-                                 kept.value, streamed.value)
-    assert words((32, 32), 8, 64)[1:] == (132, 296) and words((32, 32), 16, 64)[1:] == (268, 160) and words((32, 32), 11, 64)[1:] == (176, 252)
-    assert words((32, 32), 32, 64)[1:] == (428, 0) and words((16, 16), 8, 64)[1:] == (132, 24)   # everything / nearly everything kept (three words straddle two wavefronts' rows)
-    assert words((32, 32), 16, 4)[1:] == (0, 425) and words((32, 32), 4, 64)[1:] == (0, 425)   # short launches and other geometries keep nothing
-    assert words((64, 64, 64), 8, 64)[1:] == (0, 2401) and words((32, 32), 3, 64)[0] == SIZE
+    in_lds, in_regs, streamed = C.c_int64(), C.c_int64(), C.c_int64()
+    words = lambda h, w, steps: (lib.ld_fly_steps_kept_words_f32(C.byref(MlpSpec.from_hidden(h)), w, steps, C.byref(in_lds), C.byref(in_regs),
+                                                                 C.byref(streamed)), in_lds.value, in_regs.value, streamed.value)
+    # (gene words per drone kept in LDS, held in registers, loaded every timestep): 32-32 has 428 (three words straddle two
+    # wavefronts' rows and are loaded by both)
+    assert words((32, 32), 8, 64)[1:] == (132, 96, 200) and words((32, 32), 16, 64)[1:] == (268, 112, 48) and words((32, 32), 11, 64)[1:] == (176, 96, 156)
+    assert words((32, 32), 32, 64)[1:] == (428, 0, 0) and words((16, 16), 8, 64)[1:] == (132, 24, 0)   # everything on chip
+    assert words((32, 32), 16, 4)[1:] == (0, 0, 425) and words((32, 32), 4, 64)[1:] == (0, 0, 425)   # short launches and other geometries keep nothing
+    assert words((64, 64, 64), 8, 64)[1:] == (0, 0, 2401) and words((32, 32), 3, 64)[0] == SIZE
     # ... and without the kept genes (ld_debug_lds_keep(0)): tiles of ~112 MB of genes that the Infinity Cache holds
     assert lib.ld_debug_lds_keep(0) == -1
     assert geo((32, 32), 65536, 2000) == (OK, 64, 4, 128, 16384) and geo((32, 32), 32768, 4000) == (OK, 64, 4, 126, 16384)
-    assert words((32, 32), 16, 64)[1:] == (0, 425)
+    assert words((32, 32), 16, 64)[1:] == (0, 0, 425)
     assert lib.ld_debug_lds_keep(-1) == 0
     assert geo((64, 64, 64), 131072, 4000) == (OK, 64, 8, 63, 131072)     # 38 KB of genes per drone: a tile could not fill the chip; two workgroups of 4
     assert geo((64, 64, 64), 8192, 100) == (OK, 64, 8, 2, 8192) and geo((12,), 1000, 50) == (OK, 64, 1, 1, 1000)   # run-time spec: one wavefront per block, 64 timesteps per launch
@@ -264,12 +266,12 @@ def test_no_fused_step_kernel_runs_out_of_scratch():
     repo = Path(__file__).resolve().parent.parent
     out = subprocess.run([sys.executable, str(repo / "scripts" / "audit_scratch.py")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
-    assert "fly_split_kernel<float, false, 4, 1, 0, 32, 32>" in out.stdout and "fly_split_kernel<float, false, 8, 2, 0, 32, 32>" in out.stdout
+    assert "fly_split_kernel<float, false, 4, 1, 0, 0, 32, 32>" in out.stdout and "fly_split_kernel<float, false, 8, 2, 0, 0, 32, 32>" in out.stdout
     # the variants that keep 136 KiB of a workgroup's genes in LDS (workgroups of 64, 32, 48 and 16 drones): none of
     # those the launch policy picks uses scratch
     for spec in ("32, 32", "16, 16", "24, 24", "16", "32"):
         for geometry in ("8, 1", "8, 2", "8, 3", "8, 4"):
-            line = [l for l in out.stdout.splitlines() if l.startswith(f"fly_split_kernel<float, false, {geometry}, 136, {spec}>")]
+            line = [l for l in out.stdout.splitlines() if re.match(rf"fly_split_kernel<float, false, {geometry}, 136, \d+, {spec}>\s", l)]
             assert len(line) == 1 and line[0].endswith("scratch 0"), (spec, geometry, line)
     assert "fly_resident_kernel" in out.stdout
 

@@ -216,17 +216,18 @@ int auto_waves_per_block(const ld_mlp_spec* spec, int64_t n, int32_t n_steps)
 {
     const int64_t blocks = (n + 63) / 64;
     if (keeps_genes(spec, n_steps)) {
-        // A workgroup of 8 wavefronts keeps 136 KiB of its drones' genes in LDS and has its CU to itself, so 256 workgroups
-        // are resident at a time and what they STREAM per timestep should fit the L2s (32 MB): then the stream never
-        // reaches the Infinity Cache fabric and a timestep takes what its dependent chain takes (3.2-3.8 us for 32-32).
-        // Workgroups of 64 / 32 / 16 drones keep 136 / 272 / 544 gene words per drone and stream 16 (W - kept) bytes for
-        // each of 16 384 / 8 192 / 4 096 resident drones: within ~24 MB for W <= 227 / 455 / any.  Measured, 32-32 (W = 425),
-        // us per timestep at 8 / 16 / 32 wavefronts per block: 65 536 drones in one launch 40.8 / 29.4 / 52.2, 8 192: 6.8 /
-        // 3.8 / 6.6, 4 096: 5.9 / 3.6 / 3.2 (profiles/r03_lds_keep.json).  Small launches then take the workgroups per
-        // block that give every CU one.
+        // A workgroup of 8 wavefronts keeps 136 KiB of its drones' genes in LDS, holds 12-14 more words per wavefront in
+        // registers, and has its CU to itself, so 256 workgroups are resident at a time and what they STREAM per timestep
+        // should fit the L2s (32 MB): then the stream never reaches the Infinity Cache fabric and a timestep takes what its
+        // dependent chain takes (2.9-3.0 us for 32-32).  Workgroups of 64 / 32 drones keep 228 / 380 gene words per drone on
+        // chip and stream 16 (W - kept) bytes for each of 16 384 / 8 192 resident drones: within ~28 MB for W <= 335 / any
+        // net of up to 512 words.  Measured, us per timestep of 65 536 drones in one launch at 8 / 16 / 32 wavefronts per
+        // block (scripts/exp_lds_keep5.py, profiles/r03_lds_keep.json): 32-32 (W = 425) 27.9 / 23.3 / 49.8, 64 (321) 17.0 /
+        // 20.5 / 42.2, 24-24 (271) 12.1 / 18.8 / 37.4, 16-16 (149) 8.0 / 15.2 / 20.3.  A launch too small to give every CU
+        // a workgroup of 64 drones takes workgroups of 32 (8 192 x 24-24: 2.77 -> 2.45 us per timestep; 1 024 x 32-32: 4.57
+        // -> 2.93); workgroups of 16 (everything in LDS, nothing in registers) never won (1 024 x 32-32: 3.17).
         const int64_t words = ld_mlp_words_per_drone(spec);
-        int groups = words <= 227 ? 1 : (words <= 455 ? 2 : 4);
-        while (groups < 4 && blocks * groups < 256) groups *= 2;
+        const int groups = (words <= 335 && blocks >= 256) ? 1 : 2;
         return 8 * groups;
     }
     const int64_t target = n_steps > 1 ? 2048 : 1024;

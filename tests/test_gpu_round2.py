@@ -594,7 +594,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     top = max(r["levels"].values(), key=lambda v: v["frac"])
     assert r["frac"] == top["frac"] and r["achieved"] == top["achieved"] and r["peak"] == top["peak"] and 0 < r["frac"] <= 1.0
     assert r["levels"]["hbm"]["peak"] == 8000.0 and r["unit"] in ("GB/s", "G wave-instructions/s")
-    assert r["launch_us"] > 0 and "traffic" in r and r["lds_words_per_drone"] == 428 and r["streamed_words_per_drone"] == 0   # 4 096 drones: 16 per workgroup
+    assert r["launch_us"] > 0 and "traffic" in r and r["lds_words_per_drone"] == 268 and r["register_words_per_drone"] == 112 and r["streamed_words_per_drone"] == 48   # workgroups of 32 drones
     assert "roofline_hbm_bound" in d and d["one_timestep_per_launch"]["bound"] == "hbm"
     assert "exchange_bytes_per_generation_per_rank" in d["generation"]
     c = d["cpu_baseline"]

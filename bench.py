@@ -392,23 +392,32 @@ def main():
         roof["copy_ceiling_gbs"] = 10 * 2 * src_buf.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del src_buf, dst_buf
 
-    # The HBM-bound form of the same kernel family: 64 timesteps per launch over the whole population with NOTHING kept on
-    # chip (no genes in LDS, no tiles for the Infinity Cache), so every timestep's genes come from HBM -- what BASELINE's
-    # ">= 60 % of the HBM roofline on the fused step kernel" asks about.  And the round-2 rollout (Infinity-Cache tiles,
-    # nothing kept in LDS) for comparison.
+    # The HBM-bound form of the fused step is the literal contract launch above -- one timestep per launch: the population's
+    # genes (446 MB) exceed the 256 MiB Infinity Cache, so every launch streams all of them from HBM (PMC: traffic = 1.001 x
+    # algorithmic) -- and that is what BASELINE's ">= 60 % of the HBM roofline on the fused step kernel" asks about.
     hbm_bound = None
+    if "one_timestep_per_launch" in extras and pop.local.bytes_per_launch(1) > 300e6:
+        hbm_bound = dict(extras["one_timestep_per_launch"])
+        hbm_bound["kernel"] = "fly_split_kernel<float, %d wavefront(s) per block, nothing kept, %s>, one timestep per launch" % (
+            pop.local.auto_waves_per_block(n_local, 1), "-".join(map(str, hidden)))
+        for f in sorted((REPO / "profiles").glob("r*_c3_k1_pmc.json"), reverse=True):
+            prof = json.loads(f.read_text())
+            if prof.get("config", {}).get("drones") == n_local and tuple(prof["config"]["hidden"]) == hidden and prof.get("per_launch", {}).get("fabric_bytes"):
+                hbm_bound["traffic"], hbm_bound["counters_source"] = prof["per_launch"]["fabric_bytes"], f"profiles/{f.name}"
+                break
+        hbm_bound.setdefault("traffic", None)
+    # Between the two: 64 timesteps per launch with NOTHING kept in LDS or registers (ld_debug_lds_keep(0)) -- whole-population
+    # launches, whose resident workgroups re-stream 111 MB of genes from the Infinity Cache, and the round-2 rollout
+    # (Infinity-Cache tiles): both bound by the fabric between that cache and the L2s.
     if not args.no_extras and roof["kept_words_per_drone"] > 0 and 4 * pop.local.P * n_local > 300e6:
         _, _, dt_w, roof_w = measure(n_local, args.steps, 1, force_tile=n_local, keep=False)
-        hbm_bound = {"bound": "hbm", "achieved": roof_w["algorithmic_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": roof_w["algorithmic_gbs"] / HBM_PEAK_GBS, "launch_us": roof_w["launch_us"], "bytes_per_launch": roof_w["bytes_per_launch"],
-                     "kernel": roof_w["kernel"], "timesteps_per_launch": roof_w["timesteps_per_launch"],
-                     "wavefronts_per_block": roof_w["wavefronts_per_block"], "drones_per_launch": roof_w["drones_per_launch"],
-                     "value": n_local * world * T * args.steps / dt_w, "ms_per_step": dt_w / args.steps * 1e3,
-                     "note": "the same fused step with nothing kept on chip: whole-population launches (446 MB of genes, re-streamed "
-                             "from HBM every timestep), ld_debug_lds_keep(0); algorithmic bytes / HIP-event launch time against the HBM peak"}
         close_roofline(roof_w, n_local)
-        hbm_bound["traffic"] = roof_w.get("traffic")
-        hbm_bound["counters_source"] = roof_w.get("counters_source")
+        extras["nothing_kept_on_chip"] = {"value": n_local * world * T * args.steps / dt_w, "unit": "drone-steps/s", "ms_per_step": dt_w / args.steps * 1e3,
+                                          "roofline": {k: roof_w.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "launch_us", "bytes_per_launch",
+                                                                                  "algorithmic_gbs", "traffic", "counters_source", "kernel",
+                                                                                  "timesteps_per_launch", "wavefronts_per_block", "drones_per_launch")},
+                                          "note": "whole-population launches of 64 timesteps, ld_debug_lds_keep(0): every gene word requested from the "
+                                                  "L2s every timestep; 256 workgroups are resident and re-stream their 111 MB from the Infinity Cache"}
         _, _, dt_t, roof_t = measure(n_local, args.steps, 1, keep=False)
         extras["without_kept_genes"] = {"value": n_local * world * T * args.steps / dt_t, "unit": "drone-steps/s", "ms_per_step": dt_t / args.steps * 1e3,
                                         "launch_us": roof_t["launch_us"], "drones_per_launch": roof_t["drones_per_launch"],

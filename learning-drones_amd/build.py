@@ -154,7 +154,7 @@ def build_specialisation(hidden, verbose: bool = False) -> Path:
     src, lib = JIT_DIR / f"ld_spec_{tag}.hip", JIT_DIR / f"libld_spec_{tag}.so"
     keep = keeps_in_lds(hidden)
     text = (f"// generated by learning_drones_amd.build.build_specialisation({hidden})\n"
-            f"#define LD_TAG jit_{tag}\n#define LD_WIDTHS {widths}\n#define LD_ONLY_F32\n#define LD_NO_CACHED_SPLIT\n"
+            f"#define LD_TAG jit_{tag}\n#define LD_WIDTHS {widths}\n#define LD_ONLY_F32\n"
             + ("#define LD_SPLIT_HAS_KEEP\n" if keep else "") +
             f'#include "{CSRC}/ld_unrolled.inc"\n#include "{CSRC}/ld_split.inc"\n#include "{CSRC}/ld_resident.hpp"\n'
             'extern "C" int ld_spec_fly_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, const double* coins, '

@@ -20,6 +20,7 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 
 #include "ld_kernels.hpp"
@@ -308,16 +309,22 @@ int launch_fly_resident(const ld_sim_params* sim, const ld_episode_params* ep, c
 {
     constexpr int G = 64 / L;
     // persistent grid: as many wavefronts as the chip holds at once (or fewer, for a small population)
-    static int resident_blocks = 0;
-    if (resident_blocks == 0) {
+    // (sized once, for the device of the first launch's stream: the work queue makes any grid size correct, the size
+    // only decides how well the chip is filled, and the GPUs of one node are alike; an atomic, so that two host
+    // threads may get here together)
+    static std::atomic<int> resident_blocks{0};
+    int grid = resident_blocks.load(std::memory_order_relaxed);
+    if (grid == 0) {
         int per_cu = 0, dev = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fly_resident_kernel<Real, Faithful, L, H...>, 64, 0) != hipSuccess || per_cu < 1)
             per_cu = 4;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+        const hipError_t where = stream ? hipStreamGetDevice(stream, &dev) : hipGetDevice(&dev);
+        if (where != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
             cus = 256;
-        resident_blocks = per_cu * cus;
+        grid = per_cu * cus;
+        resident_blocks.store(grid, std::memory_order_relaxed);
     }
-    const unsigned blocks = (unsigned)std::min<int64_t>(blocks_for(n, G), resident_blocks);
+    const unsigned blocks = (unsigned)std::min<int64_t>(blocks_for(n, G), grid);
     hipError_t e = hipMemsetAsync(queue, 0, sizeof(int32_t), stream);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(queue)");
     hipLaunchKernelGGL((fly_resident_kernel<Real, Faithful, L, H...>), dim3(blocks), dim3(64), 0, stream, make_sim<Real>(*sim),

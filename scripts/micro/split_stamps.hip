@@ -41,7 +41,7 @@ int run(int64_t n, int steps, int reps)
         CHECK(hipMemcpyToSymbol(HIP_SYMBOL(ld::ld_diag_cycles), zero, sizeof zero));
         if (ld_population_reset_f32(fstate, istate, n, nullptr, nullptr)) return 1;
         CHECK(hipEventRecord(e0, nullptr));
-        if (ld::launch_fly_split<float, false, 8, S, Keep, 0, 32, 32>(&sim, &ep, coins, nullptr, genomes, fstate, istate, n, 0, n, steps, nullptr)) return 1;
+        if (ld::launch_fly_split<float, false, 8, S, Keep, (Keep == 0 ? 0 : S == 1 ? LD_SPLIT_REG_WORDS_64 : S == 2 ? LD_SPLIT_REG_WORDS_32 : S == 3 ? LD_SPLIT_REG_WORDS_48 : 0), 32, 32>(&sim, &ep, coins, nullptr, genomes, fstate, istate, n, 0, n, steps, nullptr)) return 1;
         CHECK(hipEventRecord(e1, nullptr));
         CHECK(hipDeviceSynchronize());
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -49,7 +49,7 @@ int run(int64_t n, int steps, int reps)
     }
     unsigned long long got[8][8];
     CHECK(hipMemcpyFromSymbol(got, HIP_SYMBOL(ld::ld_diag_cycles), sizeof got));
-    std::printf("drones %lld S %d keep %d KiB: %.1f us per launch of %d timesteps (%.2f us per timestep, stamps included)\n",
+    std::printf("drones %lld workgroups-per-block code %d (3 = 48 drones per workgroup) keep %d KiB (+ the shipped register words): %.1f us per launch of %d timesteps (%.2f us per timestep, stamps included)\n",
                 (long long)n, S, Keep, ms_best * 1e3, steps, ms_best * 1e3 / steps);
     const char* seg[7] = {"top -> physics done", "layer 1 work", "layer 1 barrier", "layer 2 work", "layer 2 barrier", "layer 3 work", "layer 3 barrier"};
     for (int w = 0; w < 8; ++w) {

@@ -269,8 +269,8 @@ int ld_fly_step_f64(const ld_sim_params *sim, const ld_episode_params *ep, const
  * With n_steps > 1 the drone
  * state stays in registers between timesteps and the genes are re-streamed every step (from L2 /
  * Infinity Cache when the shard's genomes fit there): no per-step kernel boundary and 200/n_steps
- * instead of 200 bytes of state traffic per drone-step.  With n_steps >= 8, for nets of up to 512 gene words whose
- * hidden layers split evenly over 8 wavefronts, the workgroups of 8 wavefronts (waves_per_block 8, 11, 16, 32)
+ * instead of 200 bytes of state traffic per drone-step.  With n_steps >= 8, for nets of up to 512 gene words,
+ * the workgroups of 8 wavefronts (waves_per_block 8, 11, 16, 32)
  * also KEEP 136 KiB of their drones' genes in the CU's LDS for the whole launch (loaded once, read back from LDS
  * every timestep: 31 / 41 / 63 / 100 % of a 32-32 net's genes at 64 / 48 / 32 / 16 drones per workgroup) and hold up
  * to 12-14 more gene words per wavefront in registers, so only the rest is re-streamed (32-32 at 32 drones per

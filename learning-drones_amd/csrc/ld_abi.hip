@@ -166,7 +166,7 @@ bool even_split(const ld_mlp_spec* spec, int waves_per_workgroup)
 }
 
 // Launches that keep genes in LDS (fly_split_kernel<..., KeepKiB>; n_steps >= LD_KEEP_MIN_STEPS, nets of up to 512 gene
-// words with an even split over 8 wavefronts): a workgroup of 8 wavefronts fills its CU's LDS with 136 KiB of its drones'
+// words): a workgroup of 8 wavefronts fills its CU's LDS with 136 KiB of its drones'
 // genes, so what matters is that every CU has exactly one workgroup: the fewest workgroups per block that give the
 // launch 256 of them.  32-32, 64 timesteps per launch, us per launch at 8 / 16 / 32 wavefronts per block
 // (scripts/exp_lds_keep.py, profiles/r03_lds_keep.json): 16 384 drones 598 / 700 / 841 (without keeping: 817 / 885 / 1 503),
@@ -174,7 +174,10 @@ bool even_split(const ld_mlp_spec* spec, int waves_per_workgroup)
 // (3 760 / 3 668 / 6 034).
 bool keeps_genes(const ld_mlp_spec* spec, int32_t n_steps)
 {
-    return keep_bit(n_steps) != 0 && ld_mlp_words_per_drone(spec) <= 512 && even_split(spec, 8);
+    // (uneven row splits included: 10-10, the reference's own controller, 7.3 us per timestep of 65 536 drones against
+    // 9.5 in its best geometry without; the keeping kernels' translation units are always built without the
+    // common-code sinking that put the uneven splits' gene rings in scratch)
+    return keep_bit(n_steps) != 0 && ld_mlp_words_per_drone(spec) <= 512;
 }
 
 // What KeepPlan<8, ...> (ld_split.hpp) works out at compile time, at run time, for the accounting entry point

@@ -204,9 +204,13 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ld_debug_lds_keep(-1) == 0
     assert geo((64, 64, 64), 131072, 4000) == (OK, 64, 8, 63, 131072)     # 38 KB of genes per drone: a tile could not fill the chip; two workgroups of 4
     assert geo((64, 64, 64), 8192, 100) == (OK, 64, 8, 2, 8192) and geo((12,), 1000, 50) == (OK, 64, 1, 1, 1000)   # run-time spec: one wavefront per block, 64 timesteps per launch
-    assert geo((10, 10), 65536, 2000) == (OK, 64, 2, 32, 65536)           # 82 MB: fits as it is; 10 rows split evenly over 2 wavefronts only
-    assert geo((10, 10), 1024, 2000)[2] == 2 and geo((8, 8), 1024, 2000)[2] == 4
-    assert geo((10, 10), 1048576, 100)[4] == 65536
+    assert geo((10, 10), 65536, 2000) == (OK, 64, 8, 32, 65536)           # the reference's own controller: 79 gene words, all of them kept on chip
+    assert geo((10, 10), 1024, 2000)[2] == 16 and geo((8, 8), 1024, 2000)[2] == 16
+    assert geo((10, 10), 1048576, 100)[4] == 1048576                      # launches that keep their genes are not tiled
+    assert lib.ld_debug_lds_keep(0) == -1
+    assert geo((10, 10), 65536, 2000) == (OK, 64, 2, 32, 65536)           # nothing kept: 82 MB fits the Infinity Cache as it is; 10 rows split evenly over 2 wavefronts only
+    assert geo((10, 10), 1024, 2000)[2] == 2 and geo((8, 8), 1024, 2000)[2] == 4 and geo((10, 10), 1048576, 100)[4] == 65536
+    assert lib.ld_debug_lds_keep(-1) == 0
     assert lib.ld_fly_rollout_geometry_f32(C.byref(spec), 8, 8, None, None, None, None) == NULL
     for sfx in ("f32", "f64"):
         acc = getattr(lib, f"ld_accelerations_{sfx}")
@@ -249,7 +253,7 @@ def test_runtime_specialisation_builds_and_registers(lib):
     k, w, m = C.c_int32(), C.c_int32(), C.c_int32()
     tile = C.c_int64()
     assert lib.ld_fly_rollout_geometry_f32(C.byref(spec), 8192, 2000, C.byref(k), C.byref(w), C.byref(m), C.byref(tile)) == 0
-    assert (k.value, w.value, m.value, tile.value) == (64, 2, 32, 8192)                    # the specialised spec takes the multi-step geometry (13 and 7 rows: two wavefronts at most)
+    assert (k.value, w.value, m.value, tile.value) == (64, 16, 32, 8192)                   # the specialised spec takes the multi-step, gene-keeping geometry (workgroups of 32 drones: 8 192 drones are 128 blocks)
     assert lib.ld_debug_force_generic(1) == 0 and lib.ld_has_specialisation_f32(C.byref(spec)) == 0
     assert lib.ld_debug_force_generic(0) == 1
     # the entry points validate like the built-in ones (n == 0 is a no-op, no kernel is launched without a GPU)
@@ -270,7 +274,7 @@ def test_no_fused_step_kernel_runs_out_of_scratch():
     assert "fly_split_kernel<float, false, 4, 1, 0, 0, 32, 32>" in out.stdout and "fly_split_kernel<float, false, 8, 2, 0, 0, 32, 32>" in out.stdout
     # the variants that keep 136 KiB of a workgroup's genes in LDS (workgroups of 64, 32, 48 and 16 drones): none of
     # those the launch policy picks uses scratch
-    for spec in ("32, 32", "16, 16", "24, 24", "16", "32"):
+    for spec in ("32, 32", "16, 16", "24, 24", "16", "32", "64", "10, 10", "8, 8", "8, 10"):
         for geometry in ("8, 1", "8, 2", "8, 3", "8, 4"):
             line = [l for l in out.stdout.splitlines() if re.match(rf"fly_split_kernel<float, false, {geometry}, 136, \d+, {spec}>\s", l)]
             assert len(line) == 1 and line[0].endswith("scratch 0"), (spec, geometry, line)

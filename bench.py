@@ -8,8 +8,8 @@
 Workload (BASELINE config 3, the one the metric is quoted on): 65 536 drones per GPU x 2 000
 timesteps, 15-32-32-4 controller, 3-coin chain, crash penalty on, float32.  A "step" is one whole
 episode of the population = the fused-step launches of ld_fly_rollout_f32 (32 launches of 64 timesteps over all
-65 536 drones, the drone state in registers in between; workgroups of 8 wavefronts fly 32 drones each and keep
-136 KiB of their genes in LDS for the launch) + the finalize launch (+ the RCCL all-gather of the
+65 536 drones, the drone state in registers in between; workgroups of 8 wavefronts fly 32 drones each, both halves of
+every wavefront summing rows of the controller, and hold their drones' genes in registers and LDS for the launch) + the finalize launch (+ the RCCL all-gather of the
 16-byte fitness records when N > 1).  Population shards are independent, so the headline line is weak
 scaling: every rank owns 65 536 drones.  With N > 1 the same run ALSO times the strong-scaling case
 BASELINE's target describes (ONE 65 536-drone population split over the N GPUs) and reports it in the
@@ -271,8 +271,11 @@ def main():
                     "in registers cost no traffic at all)",
                     "achieved": lds_bytes / launch_s / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s"},
         }
-        roof = {"kernel": ("fly_split_kernel<float, %d wavefronts per block, %s KiB of genes kept in LDS, %s>"
-                           % (geo["waves_per_block"], "136" if in_lds else "0", "-".join(map(str, hidden)))
+        paired = kept > 0 and geo["waves_per_block"] == 16 and any(h % 16 == 0 for h in hidden)
+        roof = {"kernel": (("fly_pair_kernel<%s> (workgroups of 8 wavefronts x 32 drones, both halves of a wavefront summing rows; "
+                            "%d gene words per drone in registers, %d in LDS)" % ("-".join(map(str, hidden)), in_regs, in_lds)) if paired else
+                           "fly_split_kernel<float, %d wavefronts per block, %d + %d gene words per drone kept in LDS + registers, %s>"
+                           % (geo["waves_per_block"], in_lds, in_regs, "-".join(map(str, hidden))))
                            if geo["steps_per_launch"] > 1 or geo["waves_per_block"] > 1 or pop.local.has_resident_engine()
                            else "fly_step_kernel<float, GenericNet> (run-time layer spec)"),
                 "launch_us": launch_ms * 1e3, "bytes_per_launch": bytes_per_launch, "algorithmic_gbs": bytes_per_launch / launch_s / 1e9,

@@ -35,7 +35,7 @@ using ld::launch_mlp;
 namespace {
 
 std::atomic<int> g_force_generic{0};          // ld_debug_force_generic
-std::atomic<int> g_lds_keep{-1};              // ld_debug_lds_keep: -1 = the library's choice, 0 = never, 1 = always
+std::atomic<int> g_lds_keep{-1};              // ld_debug_lds_keep: -1 = the library's choice, 0 = never, 1 = always, 2 = always, halves of a wavefront not paired
 
 // Launches of this many timesteps or more keep part of every block's genes in LDS (fly_split_kernel<..., KeepKiB>):
 // the one-off fill costs about one timestep's worth of that share.
@@ -46,7 +46,7 @@ std::atomic<int> g_lds_keep{-1};              // ld_debug_lds_keep: -1 = the lib
 int keep_bit(int32_t n_steps)
 {
     const int mode = g_lds_keep.load(std::memory_order_relaxed);
-    return mode == 0 ? 0 : (mode > 0 || n_steps >= LD_KEEP_MIN_STEPS) ? 0x100 : 0;
+    return mode == 0 ? 0 : (mode > 0 || n_steps >= LD_KEEP_MIN_STEPS) ? (mode == 2 ? 0x300 : 0x100) : 0;
 }
 
 // Specs specialised at run time (ld_register_specialisation_f32): the library's other process-wide state.
@@ -179,6 +179,15 @@ bool keeps_genes(const ld_mlp_spec* spec, int32_t n_steps)
     // common-code sinking that put the uneven splits' gene rings in scratch)
     return keep_bit(n_steps) != 0 && ld_mlp_words_per_drone(spec) <= 512;
 }
+
+// keep_words_<TAG>: the spec's own accounting function where it has gene-keeping kernels
+#define X(TAG) int keep_words_##TAG(int32_t w, int32_t np, int64_t* a, int64_t* b, int64_t* c) { return ld_u_split_keep_words_##TAG(w, np, a, b, c); }
+LD_FOR_EACH_KEEPING(X)
+#undef X
+int keep_words_64_64_64(int32_t, int32_t, int64_t*, int64_t*, int64_t*) { return LD_ERR_SPEC; }      // (wider than 512 words: never asked)
+int keep_words_48_48(int32_t, int32_t, int64_t*, int64_t*, int64_t*) { return LD_ERR_SPEC; }
+int keep_words_64_64(int32_t, int32_t, int64_t*, int64_t*, int64_t*) { return LD_ERR_SPEC; }
+int keep_words_32_32_32(int32_t, int32_t, int64_t*, int64_t*, int64_t*) { return LD_ERR_SPEC; }
 
 // What KeepPlan<8, ...> (ld_split.hpp) works out at compile time, at run time, for the accounting entry point
 // ld_fly_steps_kept_words_f32: gene words per drone a launch keeps in LDS, holds in registers, and loads from memory every
@@ -657,7 +666,7 @@ int ld_version(void) { return LD_ABI_VERSION; }
 
 int ld_debug_force_generic(int on) { return g_force_generic.exchange(on ? 1 : 0); }
 
-int ld_debug_lds_keep(int mode) { return g_lds_keep.exchange(mode < 0 ? -1 : mode ? 1 : 0); }
+int ld_debug_lds_keep(int mode) { return g_lds_keep.exchange(mode < 0 ? -1 : mode > 2 ? 1 : mode); }
 
 int ld_register_specialisation_f32(const ld_mlp_spec* spec, ld_fly_steps_f32_fn fly_steps, ld_mlp_forward_f32_fn mlp_forward,
                                    ld_fly_resident_f32_fn fly_resident)
@@ -756,8 +765,17 @@ int ld_fly_steps_kept_words_f32(const ld_mlp_spec* spec, int32_t waves_per_block
     *lds_words = *register_words = 0;
     *streamed_words = ld_mlp_words_per_drone(spec);
     const int lanes = waves_per_block == 8 ? 64 : waves_per_block == 11 ? 48 : waves_per_block == 16 ? 32 : waves_per_block == 32 ? 16 : 0;
-    if (lanes && has_unrolled(*spec) && ld_mlp_words_per_drone(spec) <= 512 && keep_bit(n_steps))
+    const int keep = keep_bit(n_steps);
+    if (lanes && has_unrolled(*spec) && ld_mlp_words_per_drone(spec) <= 512 && keep) {
+        // the shipped specs answer from their kernels' own compile-time plans; a spec specialised at run time from the
+        // run-time restatement of the unpaired plan (its workgroups of 32 drones may pair the halves: then an estimate)
+#define X(TAG, ...)                                                                                          \
+        if (ld::NetShape<__VA_ARGS__>::W <= 512 && spec_is<__VA_ARGS__>(*spec))                               \
+            return keep_words_##TAG(waves_per_block, keep >> 9, lds_words, register_words, streamed_words);
+        LD_FOR_EACH_UNROLLED(X)
+#undef X
         keep_plan(*spec, lanes, lds_words, register_words, streamed_words);
+    }
     return LD_OK;
 }
 

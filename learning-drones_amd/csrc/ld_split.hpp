@@ -50,6 +50,7 @@ namespace ld {
 // Which rows, which gene words and which positions of its private word stream wavefront k has.
 template <int L, int... H> struct SplitPlan {
     using Shape = NetShape<H...>;
+    static constexpr int kL = L;
     static constexpr int NL = Shape::n_layers;
     static constexpr int row_begin(int layer, int k) { return k * Shape::dims[layer + 1] / L; }
     static constexpr int row_end(int layer, int k) { return (k + 1) * Shape::dims[layer + 1] / L; }
@@ -108,8 +109,9 @@ template <int L, int... H> struct SplitPlan {
 // otherwise re-walk a wavefront's stream for every word, minutes of compile time per kernel): the class of every stream
 // position -- 0 = kept in LDS, 1 = held in a register, 2 = loaded every timestep --, its index within its class, and the
 // position of the j-th word of each class.
-template <int L, int KeepWords, int RegWords, int... H> struct KeepPlan {
-    using Plan = SplitPlan<L, H...>;
+template <typename PlanT, int KeepWords, int RegWords, bool RegsFirst = false> struct KeepPlanOf {
+    using Plan = PlanT;
+    static constexpr int L = Plan::kL;
     static constexpr int N = Plan::max_stream_len() > 0 ? Plan::max_stream_len() : 1;
     struct Tables {
         int len[L];                 // stream length of wavefront k
@@ -128,6 +130,10 @@ template <int L, int KeepWords, int RegWords, int... H> struct KeepPlan {
             const int len = t.len[k];
             int keep = KeepWords == 0 || total == 0 ? 0 : (int)((long long)len * KeepWords / total);
             keep = keep < len ? keep : len;
+            if (RegsFirst) {                                    // registers take their words first, LDS what is left of its share
+                const int first = RegWords < len ? RegWords : len;
+                keep = keep < len - first ? keep : len - first;
+            }
             const int rest = len - keep;
             const int regs = RegWords < rest ? RegWords : rest;
             t.n[0][k] = keep; t.n[1][k] = regs; t.n[2][k] = rest - regs;
@@ -168,6 +174,18 @@ template <int L, int KeepWords, int RegWords, int... H> struct KeepPlan {
         return m;
     }
 };
+
+template <int L, int KeepWords, int RegWords, int... H> using KeepPlan = KeepPlanOf<SplitPlan<L, H...>, KeepWords, RegWords>;
+
+// Accounting (ld_fly_steps_kept_words_f32): gene words per drone a gene-keeping fly_split_kernel keeps in LDS, holds in
+// registers, loads every timestep (S as in the kernel: workgroups of 64 / 32 / 48 / 16 drones).
+template <int S, int KeepKiB, int RegWords, int... H>
+inline void split_kept_words(int64_t* lds, int64_t* regs, int64_t* streamed)
+{
+    using Keep = KeepPlan<8, KeepKiB * 1024 / ((S == 3 ? 48 : 64 / S) * 16), RegWords, H...>;
+    *lds = *regs = *streamed = 0;
+    for (int k = 0; k < 8; ++k) { *lds += Keep::T.n[0][k]; *regs += Keep::T.n[1][k]; *streamed += Keep::T.n[2][k]; }
+}
 
 // f(integral_constant<K>) for the K that equals `wave` (wave-uniform), as a switch:
 // with independent ifs the compiler must assume that a later block can run after an earlier one and
@@ -534,3 +552,7 @@ int launch_fly_split(const ld_sim_params* sim, const ld_episode_params* ep, cons
     int ld_u_split_f32_##TAG(const ld_sim_params*, const ld_episode_params*, const double*, const double*,        \
                              const float*, float*, int32_t*, int64_t, int64_t, int64_t, int32_t, int32_t, hipStream_t);
 LD_FOR_EACH_UNROLLED(LD_DECLARE_SPLIT)
+// ... and, for the specs of up to 512 gene words, what its gene-keeping kernels keep (ld_split_keep_<tag>.hip)
+#define LD_FOR_EACH_KEEPING(X) X(8_10) X(10_10) X(16_16) X(32_32) X(16) X(32) X(64) X(8_8) X(24_24)
+#define LD_DECLARE_KEEP_WORDS(TAG) int ld_u_split_keep_words_##TAG(int32_t waves_per_block, int32_t no_pairing, int64_t*, int64_t*, int64_t*);
+LD_FOR_EACH_KEEPING(LD_DECLARE_KEEP_WORDS)

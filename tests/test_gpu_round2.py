@@ -247,7 +247,7 @@ def _replicated(hidden, m, n, seed):
 def test_full_size_config4_shard(Population, torch):
     """One GPU's share of BASELINE config 4: 32 768 drones x 4 000 steps, 15-32-32-4, 3-coin chain (the
     launch geometry this shard gets: 64 timesteps per launch, all 32 768 drones in one launch, two workgroups of 8 wavefronts per
-    genome block, each keeping 268 of its 32 drones' 428 gene words in LDS and 112 in registers for the launch).  Size-independent
+    genome block, both halves of every wavefront summing rows, all of its 32 drones' genes held in registers (424 words) and LDS (12) for the launch).  Size-independent
     properties: genomes replicated from a 256-drone population under a random permutation give the
     permuted small-population results bit for bit; a re-run is bit-identical; one launch per timestep
     and the resident engine give the same records."""
@@ -261,7 +261,7 @@ def test_full_size_config4_shard(Population, torch):
     pop = Population(n, hidden, coins=coins)
     pop.set_genomes(torch.as_tensor(genes_m, dtype=torch.float32, device="cuda")[torch.as_tensor(src, device="cuda")])
     geo = pop.rollout_geometry(T)
-    assert geo == {"steps_per_launch": 64, "waves_per_block": 16, "launches": 63, "tile_drones": 32768, "lds_words": 268, "register_words": 112, "streamed_words": 48}
+    assert geo == {"steps_per_launch": 64, "waves_per_block": 16, "launches": 63, "tile_drones": 32768, "lds_words": 12, "register_words": 424, "streamed_words": 0}
     pop.fly(T)
     got = pop.results()
     for f in ("reward", "flight_time", "coins", "crashed", "distance_to_coin"):
@@ -594,7 +594,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     top = max(r["levels"].values(), key=lambda v: v["frac"])
     assert r["frac"] == top["frac"] and r["achieved"] == top["achieved"] and r["peak"] == top["peak"] and 0 < r["frac"] <= 1.0
     assert r["levels"]["hbm"]["peak"] == 8000.0 and r["unit"] in ("GB/s", "G wave-instructions/s")
-    assert r["launch_us"] > 0 and "traffic" in r and r["lds_words_per_drone"] == 268 and r["register_words_per_drone"] == 112 and r["streamed_words_per_drone"] == 48   # workgroups of 32 drones
+    assert r["launch_us"] > 0 and "traffic" in r and r["lds_words_per_drone"] == 12 and r["register_words_per_drone"] == 424 and r["streamed_words_per_drone"] == 0   # workgroups of 32 drones, halves paired
     assert "roofline_hbm_bound" in d and d["one_timestep_per_launch"]["bound"] == "hbm"
     assert "exchange_bytes_per_generation_per_rank" in d["generation"]
     c = d["cpu_baseline"]
@@ -641,7 +641,7 @@ def test_kept_genes_are_bit_identical_on_a_ragged_population(Population, torch, 
     pop = Population(n, hidden, walls=walls, coins=coin_chain_reference(2))
     pop.set_genomes(torch.as_tensor(genes_m, dtype=torch.float32, device="cuda")[torch.as_tensor(src, device="cuda")])
     geo = pop.rollout_geometry(T)
-    assert geo["tile_drones"] == n and geo["waves_per_block"] == 16 and geo["lds_words"] == 268 and geo["register_words"] == 112
+    assert geo["tile_drones"] == n and geo["waves_per_block"] == 16 and geo["lds_words"] + geo["register_words"] == 436 and geo["streamed_words"] == 0
     assert lib.ld_debug_lds_keep(0) == -1
     try:
         assert pop.rollout_geometry(T)["tile_drones"] == 16384 and pop.rollout_geometry(T)["lds_words"] == 0
@@ -652,9 +652,13 @@ def test_kept_genes_are_bit_identical_on_a_ragged_population(Population, torch, 
     crashed = (want[1][2] & 1).bool()
     assert crashed.any() and not crashed.all() and int(want[1][1].max()) >= 1
     for rep, kw in enumerate(({}, {}, dict(waves_per_block=8), dict(waves_per_block=11), dict(waves_per_block=32),
-                              dict(waves_per_block=11, tile_drones=12288), dict(steps_per_launch=9), dict(steps_per_launch=7))):
+                              dict(waves_per_block=11, tile_drones=12288), dict(steps_per_launch=9), dict(steps_per_launch=7),
+                              dict(unpaired=True))):
         pop.reset()
+        if kw.pop("unpaired", False):                                     # the same workgroups of 32 drones without the paired halves
+            assert lib.ld_debug_lds_keep(2) == -1
         pop.fly(T, **kw)
+        lib.ld_debug_lds_keep(-1)
         summed = pop.records.sum(dim=0)                                   # enqueued behind fly() on the same stream
         assert torch.equal(pop.fstate, want[0]) and torch.equal(pop.istate, want[1]) and torch.equal(pop.records, want[2]), (rep, kw)
         assert torch.equal(summed, want[2].sum(dim=0))

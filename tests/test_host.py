@@ -193,7 +193,12 @@ def test_argument_validation_without_gpu(lib):
                                                                  C.byref(streamed)), in_lds.value, in_regs.value, streamed.value)
     # (gene words per drone kept in LDS, held in registers, loaded every timestep): 32-32 has 428 (three words straddle two
     # wavefronts' rows and are loaded by both)
-    assert words((32, 32), 8, 64)[1:] == (132, 96, 200) and words((32, 32), 16, 64)[1:] == (268, 112, 48) and words((32, 32), 11, 64)[1:] == (176, 96, 156)
+    assert words((32, 32), 8, 64)[1:] == (132, 96, 200) and words((32, 32), 11, 64)[1:] == (176, 96, 156)
+    # workgroups of 32 drones pair the halves of a wavefront (ld_pair.hpp): a stream position is two gene words, 32 positions per
+    # wavefront stay in registers, LDS keeps the rest: everything on chip (436 = 425 + the words two rows' blocks share)
+    assert words((32, 32), 16, 64)[1:] == (12, 424, 0) and words((16, 16), 16, 64)[1:] == (0, 164, 0) and words((64,), 16, 64)[1:] == (100, 224, 0)
+    assert words((24, 24), 16, 64)[1:] == (268, 12, 0)                      # 24 rows: no pairing, the unpaired kernel's plan
+    assert lib.ld_debug_lds_keep(2) == -1 and words((32, 32), 16, 64)[1:] == (268, 112, 48) and lib.ld_debug_lds_keep(-1) == 2   # (the unpaired kernel of the same geometry)
     assert words((32, 32), 32, 64)[1:] == (428, 0, 0) and words((16, 16), 8, 64)[1:] == (132, 24, 0)   # everything on chip
     assert words((32, 32), 16, 4)[1:] == (0, 0, 425) and words((32, 32), 4, 64)[1:] == (0, 0, 425)   # short launches and other geometries keep nothing
     assert words((64, 64, 64), 8, 64)[1:] == (0, 0, 2401) and words((32, 32), 3, 64)[0] == SIZE
@@ -278,6 +283,9 @@ def test_no_fused_step_kernel_runs_out_of_scratch():
         for geometry in ("8, 1", "8, 2", "8, 3", "8, 4"):
             line = [l for l in out.stdout.splitlines() if re.match(rf"fly_split_kernel<float, false, {geometry}, 136, \d+, {spec}>\s", l)]
             assert len(line) == 1 and line[0].endswith("scratch 0"), (spec, geometry, line)
+    for spec in ("32, 32", "16, 16", "16", "32", "64"):                          # ... and the kernels that pair the halves of a wavefront
+        line = [l for l in out.stdout.splitlines() if re.match(rf"fly_pair_kernel<136, \d+, {spec}>\s", l)]
+        assert len(line) == 1 and line[0].endswith("scratch 0"), (spec, line)
     assert "fly_resident_kernel" in out.stdout
 
 

@@ -272,12 +272,15 @@ def main():
                     "achieved": lds_bytes / launch_s / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s"},
         }
         paired = kept > 0 and geo["waves_per_block"] == 16 and any(h % 16 == 0 for h in hidden)
-        roof = {"kernel": (("fly_pair_kernel<%s> (workgroups of 8 wavefronts x 32 drones, both halves of a wavefront summing rows; "
-                            "%d gene words per drone in registers, %d in LDS)" % ("-".join(map(str, hidden)), in_regs, in_lds)) if paired else
-                           "fly_split_kernel<float, %d wavefronts per block, %d + %d gene words per drone kept in LDS + registers, %s>"
+        if paired:
+            kernel_name = ("fly_pair_kernel<%s> (workgroups of 8 wavefronts x 32 drones, both halves of a wavefront summing rows; %d gene "
+                           "words per drone in registers, %d in LDS)" % ("-".join(map(str, hidden)), in_regs, in_lds))
+        elif geo["steps_per_launch"] > 1 or geo["waves_per_block"] > 1 or pop.local.has_resident_engine():
+            kernel_name = ("fly_split_kernel<float, %d wavefronts per block, %d + %d gene words per drone kept in LDS + registers, %s>"
                            % (geo["waves_per_block"], in_lds, in_regs, "-".join(map(str, hidden))))
-                           if geo["steps_per_launch"] > 1 or geo["waves_per_block"] > 1 or pop.local.has_resident_engine()
-                           else "fly_step_kernel<float, GenericNet> (run-time layer spec)"),
+        else:
+            kernel_name = "fly_step_kernel<float, GenericNet> (run-time layer spec)"
+        roof = {"kernel": kernel_name,
                 "launch_us": launch_ms * 1e3, "bytes_per_launch": bytes_per_launch, "algorithmic_gbs": bytes_per_launch / launch_s / 1e9,
                 "timesteps_per_launch": geo["steps_per_launch"], "wavefronts_per_block": geo["waves_per_block"],
                 "launches_per_episode": geo["launches"], "drones_per_launch": geo["tile_drones"], "tiles": tiles,

@@ -166,8 +166,9 @@ int ld_version(void);
 /* Test hook (process-wide, not part of the data path): non-zero routes every controller spec to the
  * generic run-time-spec kernels even where an unrolled specialisation exists.  Returns the old value. */
 int ld_debug_force_generic(int on);
-/* Process-wide switch for the genes a launch of several timesteps keeps in LDS (fly_split_kernel<..., KeepKiB>):
- * -1 = the library's choice (the default: launches of 8 timesteps or more), 0 = never, 1 = always.  Results do not
+/* Process-wide switch for the genes a launch of several timesteps keeps on chip (fly_split_kernel<..., KeepKiB, RegWords>,
+ * fly_pair_kernel): -1 = the library's choice (the default: launches of 8 timesteps or more), 0 = never, 1 = always,
+ * 2 = always, but workgroups of 32 drones do not pair the halves of their wavefronts (for comparison).  Results do not
  * depend on it.  Returns the old value. */
 int ld_debug_lds_keep(int mode);
 const char *ld_strerror(int status);
@@ -273,8 +274,11 @@ int ld_fly_step_f64(const ld_sim_params *sim, const ld_episode_params *ep, const
  * the workgroups of 8 wavefronts (waves_per_block 8, 11, 16, 32)
  * also KEEP 136 KiB of their drones' genes in the CU's LDS for the whole launch (loaded once, read back from LDS
  * every timestep: 31 / 41 / 63 / 100 % of a 32-32 net's genes at 64 / 48 / 32 / 16 drones per workgroup) and hold up
- * to 12-14 more gene words per wavefront in registers, so only the rest is re-streamed (32-32 at 32 drones per
- * workgroup: 48 of 428 words); ld_fly_steps_kept_words_f32 reports the split.  Results are bit-identical to n_steps
+ * to 12-14 more gene words per wavefront in registers, so only the rest is re-streamed.  Workgroups of 32 drones
+ * (waves_per_block 16) of nets with a hidden layer whose width is a multiple of 16 go further: lanes l and l + 32 of a
+ * wavefront fly the same drone and sum different rows of the controller at once, and up to 32 gene-word positions per
+ * wavefront (two words each) stay in registers (32-32: all of the genes on chip, 424 words in registers + 12 in LDS,
+ * nothing re-streamed).  ld_fly_steps_kept_words_f32 reports the split.  Results are bit-identical to n_steps
  * calls of ld_fly_step_f32 for every waves_per_block, with and without the kept genes.  ld_fly_step_f32 itself is
  * ld_fly_steps_f32(..., 1, 0, stream) for those specs. */
 int ld_fly_steps_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,

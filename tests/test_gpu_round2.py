@@ -443,7 +443,7 @@ def test_closed_loop_f64_resident_tracks_reference(Population, g3):
 
 
 # ------------------------------------------------------------------------------------------- run-time specialisation
-@pytest.mark.parametrize("hidden", [(12, 12), (20, 20), (9, 13, 11)])
+@pytest.mark.parametrize("hidden", [(12, 12), (20, 20), (9, 13, 11), (16, 32)])
 def test_runtime_specialised_spec_equals_generic_kernels(Population, torch, generic_kernels, hidden):
     """Population(..., specialise=True) compiles the unrolled kernels for a spec the library does not ship
     (hipcc at first use) and registers them; every launch geometry of the specialised kernels, and
@@ -466,8 +466,8 @@ def test_runtime_specialised_spec_equals_generic_kernels(Population, torch, gene
     assert torch.equal(pop.feed_forward(x), y_ref)
     pop.fly(T)
     assert torch.equal(pop.fstate, ref.fstate) and torch.equal(pop.istate, ref.istate) and torch.equal(pop.records, ref.records)
-    for waves, k in ((1, 1), (2, 7), (8, 300)):
-        pop.reset()
+    for waves, k in ((1, 1), (2, 7), (8, 300), (16, 64), (11, 64), (32, 9)):   # (8 and up with >= 8 timesteps: the gene-keeping kernels;
+        pop.reset()                                                               #  16 of (16, 32): the halves of a wavefront paired)
         pop.fly(T, steps_per_launch=k, waves_per_block=waves)
         assert torch.equal(pop.records, ref.records), (waves, k)
     assert pop.has_resident_engine()                                     # the specialisation brings the resident engine too

@@ -7,7 +7,7 @@
 
 Workload (BASELINE config 3, the one the metric is quoted on): 65 536 drones per GPU x 2 000
 timesteps, 15-32-32-4 controller, 3-coin chain, crash penalty on, float32.  A "step" is one whole
-episode of the population = the fused-step launches of ld_fly_rollout_f32 (32 launches of 64 timesteps over all
+episode of the population = the fused-step launches of ld_fly_rollout_f32 (4 launches of 512 timesteps over all
 65 536 drones, the drone state in registers in between; workgroups of 8 wavefronts fly 32 drones each, both halves of
 every wavefront summing rows of the controller, and hold their drones' genes in registers and LDS for the launch) + the finalize launch (+ the RCCL all-gather of the
 16-byte fitness records when N > 1).  Population shards are independent, so the headline line is weak

@@ -364,7 +364,15 @@ int finalize_impl(const ld_episode_params* ep, const double* coins, const Real* 
 // across timesteps and dropping the per-step kernel boundary (65 536 x 32-32 in one launch: 67.6 us per
 // timestep at 1, 62.9 at 16, 62.4 at 64; 8 192: 13.3 / 9.3 / 9.0; 1 024 x 16-16: 7.7 / 2.7 / 2.5; config 3
 // in tiles: 113.3 ms per episode at 16, 109.9 at 64, 113.2 at 2 000), with nothing left beyond 64.
-int auto_steps_per_launch() { return LD_STEPS_PER_LAUNCH; }
+// Launches that hold their genes on chip pay one pass over the genes per LAUNCH (the fill), so they take more timesteps:
+// config 3, ms per episode at 64 / 128 / 256 / 500 / 2 000 timesteps per launch: 34.5 / 33.4 / 32.9 / 32.7 / 32.5.
+#ifndef LD_STEPS_PER_LAUNCH_KEEP
+#define LD_STEPS_PER_LAUNCH_KEEP 512
+#endif
+int auto_steps_per_launch(const ld_mlp_spec* spec)
+{
+    return spec && has_unrolled(*spec) && keeps_genes(spec, LD_STEPS_PER_LAUNCH_KEEP) ? LD_STEPS_PER_LAUNCH_KEEP : LD_STEPS_PER_LAUNCH;
+}
 
 // Drones per tile of a rollout.  A launch re-streams its drones' genes every timestep; when they exceed the
 // 256 MiB Infinity Cache (config 3: 446 MB) every timestep comes from HBM.  Flown tile by tile -- a tile's
@@ -396,7 +404,7 @@ int rollout_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, con
     if (!valid_waves(waves)) return LD_ERR_SIZE;
     int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
     if (rc || n == 0) return rc;
-    if (steps_per_launch == 0) steps_per_launch = auto_steps_per_launch();
+    if (steps_per_launch == 0) steps_per_launch = auto_steps_per_launch(spec);
     if (!has_unrolled(*spec)) {                     // run-time layer spec: one wavefront per block, whole-population launches
         if (waves > 1) return LD_ERR_SPEC;
         for (int32_t t = 0; t < timesteps; t += steps_per_launch) {
@@ -433,7 +441,7 @@ int rollout_impl(const ld_sim_params* sim, const ld_episode_params* ep, const ld
     // float64, and float32 layer specs without a specialisation: the one-wavefront-per-block kernel, the same
     // number of timesteps per launch (state in registers in between; no tiles: one wavefront per block needs the
     // whole population to fill the chip)
-    const int32_t per_launch = auto_steps_per_launch();
+    const int32_t per_launch = auto_steps_per_launch(nullptr);          // (float64, run-time layer specs: nothing is kept on chip)
     int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
     if (rc) return rc;
     for (int32_t t = 0; t < timesteps; t += per_launch) {
@@ -747,7 +755,7 @@ int ld_fly_rollout_geometry_f32(const ld_mlp_spec* spec, int64_t n, int32_t time
     if (n < 0 || timesteps < 0) return LD_ERR_SIZE;
     if (!steps_per_launch || !waves_per_block || !n_launches || !tile_drones) return LD_ERR_NULL;
     const bool split = has_unrolled(*spec);
-    *steps_per_launch = auto_steps_per_launch();
+    *steps_per_launch = auto_steps_per_launch(spec);
     *tile_drones = split && n > 0 ? auto_tile_drones(spec, n, *steps_per_launch) : n;
     *waves_per_block = split ? auto_waves_per_block(spec, *tile_drones, *steps_per_launch) : 1;
     const int64_t tiles = *tile_drones > 0 ? (n + *tile_drones - 1) / *tile_drones : 1;

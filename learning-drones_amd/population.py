@@ -345,8 +345,8 @@ class Population:
         _native.check(_native.lib().ld_fly_rollout_geometry_f32(C.byref(self.spec), self.n, int(timesteps), C.byref(k),
                                                                 C.byref(w), C.byref(m), C.byref(tile)),
                       "ld_fly_rollout_geometry_f32")
-        if self.precision == "f64":             # the same timesteps per launch, one wavefront per block, no tiles
-            return {"steps_per_launch": k.value, "waves_per_block": 1, "launches": -(-int(timesteps) // k.value), "tile_drones": self.n,
+        if self.precision == "f64":             # 64 timesteps per launch (nothing is kept on chip), one wavefront per block, no tiles
+            return {"steps_per_launch": 64, "waves_per_block": 1, "launches": -(-int(timesteps) // 64), "tile_drones": self.n,
                     "lds_words": 0, "register_words": 0, "streamed_words": self.W}
         lds, regs, streamed = self.kept_words(w.value, min(k.value, int(timesteps)))
         return {"steps_per_launch": k.value, "waves_per_block": w.value, "launches": m.value, "tile_drones": tile.value,

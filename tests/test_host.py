@@ -184,10 +184,11 @@ def test_argument_validation_without_gpu(lib):
     # nets of up to 512 gene words that split evenly over 8 wavefronts keep 136 KiB of genes per workgroup in LDS: no tiles,
     # workgroups of 8 wavefronts, as many per block as keep the resident workgroups' stream within the L2s (32-32: two; 16-16: one,
     # unless the launch is too small to give every CU a workgroup of 64 drones)
-    assert geo((32, 32), 65536, 2000) == (OK, 64, 16, 32, 65536) and geo((32, 32), 8192, 2000) == (OK, 64, 16, 32, 8192)
-    assert geo((32, 32), 32768, 4000) == (OK, 64, 16, 63, 32768)          # config 4 shard
-    assert geo((32, 32), 16384, 2000) == (OK, 64, 16, 32, 16384) and geo((32, 32), 1024, 2000) == (OK, 64, 16, 32, 1024)
-    assert geo((16, 16), 65536, 2000) == (OK, 64, 8, 32, 65536) and geo((16, 16), 1024, 2000) == (OK, 64, 16, 32, 1024)   # config 2
+    # (and 512 timesteps per launch instead of 64: the genes are loaded once per launch)
+    assert geo((32, 32), 65536, 2000) == (OK, 512, 16, 4, 65536) and geo((32, 32), 8192, 2000) == (OK, 512, 16, 4, 8192)
+    assert geo((32, 32), 32768, 4000) == (OK, 512, 16, 8, 32768)          # config 4 shard
+    assert geo((32, 32), 16384, 2000) == (OK, 512, 16, 4, 16384) and geo((32, 32), 1024, 2000) == (OK, 512, 16, 4, 1024)
+    assert geo((16, 16), 65536, 2000) == (OK, 512, 8, 4, 65536) and geo((16, 16), 1024, 2000) == (OK, 512, 16, 4, 1024)   # config 2
     in_lds, in_regs, streamed = C.c_int64(), C.c_int64(), C.c_int64()
     words = lambda h, w, steps: (lib.ld_fly_steps_kept_words_f32(C.byref(MlpSpec.from_hidden(h)), w, steps, C.byref(in_lds), C.byref(in_regs),
                                                                  C.byref(streamed)), in_lds.value, in_regs.value, streamed.value)
@@ -209,7 +210,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ld_debug_lds_keep(-1) == 0
     assert geo((64, 64, 64), 131072, 4000) == (OK, 64, 8, 63, 131072)     # 38 KB of genes per drone: a tile could not fill the chip; two workgroups of 4
     assert geo((64, 64, 64), 8192, 100) == (OK, 64, 8, 2, 8192) and geo((12,), 1000, 50) == (OK, 64, 1, 1, 1000)   # run-time spec: one wavefront per block, 64 timesteps per launch
-    assert geo((10, 10), 65536, 2000) == (OK, 64, 8, 32, 65536)           # the reference's own controller: 79 gene words, all of them kept on chip
+    assert geo((10, 10), 65536, 2000) == (OK, 512, 8, 4, 65536)           # the reference's own controller: 79 gene words, all of them kept on chip
     assert geo((10, 10), 1024, 2000)[2] == 16 and geo((8, 8), 1024, 2000)[2] == 16
     assert geo((10, 10), 1048576, 100)[4] == 1048576                      # launches that keep their genes are not tiled
     assert lib.ld_debug_lds_keep(0) == -1
@@ -258,7 +259,7 @@ def test_runtime_specialisation_builds_and_registers(lib):
     k, w, m = C.c_int32(), C.c_int32(), C.c_int32()
     tile = C.c_int64()
     assert lib.ld_fly_rollout_geometry_f32(C.byref(spec), 8192, 2000, C.byref(k), C.byref(w), C.byref(m), C.byref(tile)) == 0
-    assert (k.value, w.value, m.value, tile.value) == (64, 16, 32, 8192)                   # the specialised spec takes the multi-step, gene-keeping geometry (workgroups of 32 drones: 8 192 drones are 128 blocks)
+    assert (k.value, w.value, m.value, tile.value) == (512, 16, 4, 8192)                   # the specialised spec takes the multi-step, gene-keeping geometry (workgroups of 32 drones: 8 192 drones are 128 blocks)
     assert lib.ld_debug_force_generic(1) == 0 and lib.ld_has_specialisation_f32(C.byref(spec)) == 0
     assert lib.ld_debug_force_generic(0) == 1
     # the entry points validate like the built-in ones (n == 0 is a no-op, no kernel is launched without a GPU)

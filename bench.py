@@ -272,7 +272,20 @@ def main():
                     "achieved": lds_bytes / launch_s / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s"},
         }
         paired = kept > 0 and geo["waves_per_block"] == 16 and any(h % 16 == 0 for h in hidden)
-        if paired:
+        wide = kept > 0 and streamed == 0 and geo["waves_per_block"] == 8 and pop.local.flies_wide()
+        if wide:
+            # the layer outputs (and the angles' sin / cos) that cross wavefronts through LDS: every wavefront reads every hidden
+            # layer's outputs, four read the last hidden layer's, every one the 4 thrusts and the 6 sin / cos values; written once
+            xch_words = 8 * sum(hidden[:-1]) + 4 * hidden[-1] + 8 * 10 + sum(hidden) + 4 + 6
+            lds_bytes += drones_per_launch_avg * steps_per_launch_avg * 4 * xch_words
+            levels["lds"]["bytes_per_launch"] = lds_bytes
+            levels["lds"]["achieved"] = lds_bytes / launch_s / 1e9
+            levels["lds"]["source"] = ("model: the gene words kept in LDS, read back every timestep, + the layer outputs, thrusts and sin / cos "
+                                       "values that cross the workgroup's 8 wavefronts through LDS (every wavefront reads every hidden layer's outputs)")
+            kernel_name = ("fly_wide_kernel<%s> (workgroups of 8 wavefronts x 64 drones, lane = drone; %d gene words per drone in registers, "
+                           "%d in LDS, none loaded per timestep; sin / cos of the angles computed beside the output layer)"
+                           % ("-".join(map(str, hidden)), in_regs, in_lds))
+        elif paired:
             kernel_name = ("fly_pair_kernel<%s> (workgroups of 8 wavefronts x 32 drones, both halves of a wavefront summing rows; %d gene "
                            "words per drone in registers, %d in LDS)" % ("-".join(map(str, hidden)), in_regs, in_lds))
         elif geo["steps_per_launch"] > 1 or geo["waves_per_block"] > 1 or pop.local.has_resident_engine():

@@ -167,10 +167,14 @@ int ld_version(void);
  * generic run-time-spec kernels even where an unrolled specialisation exists.  Returns the old value. */
 int ld_debug_force_generic(int on);
 /* Process-wide switch for the genes a launch of several timesteps keeps on chip (fly_split_kernel<..., KeepKiB, RegWords>,
- * fly_pair_kernel): -1 = the library's choice (the default: launches of 8 timesteps or more), 0 = never, 1 = always,
- * 2 = always, but workgroups of 32 drones do not pair the halves of their wavefronts (for comparison).  Results do not
- * depend on it.  Returns the old value. */
+ * fly_pair_kernel, fly_wide_kernel): -1 = the library's choice (the default: launches of 8 timesteps or more), 0 = never,
+ * 1 = always, 2 = always, but with the kernels of before: workgroups of 32 drones do not pair the halves of their wavefronts
+ * and workgroups of 64 do not take fly_wide_kernel (for comparison).  Results do not depend on it.  Returns the old value. */
 int ld_debug_lds_keep(int mode);
+/* Test hook: the run-time restatement of fly_wide_kernel's plan (csrc/ld_wide.hpp: workgroups of 64 drones with every gene
+ * word of the block on chip) that the launch policy uses for layer specs specialised at run time.  Returns 1 and the gene
+ * words per drone kept in LDS / held in registers if the spec fits, 0 if not, or a negative ld_status. */
+int ld_debug_wide_plan(const ld_mlp_spec *spec, int64_t *lds_words, int64_t *register_words);
 const char *ld_strerror(int status);
 /* Text of the last HIP error seen by the calling thread ("" if none). */
 const char *ld_last_hip_error(void);

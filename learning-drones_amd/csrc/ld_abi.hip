@@ -8,6 +8,7 @@
 #include "ld_kernels.hpp"
 #include "ld_pid.hpp"
 #include "ld_split.hpp"
+#include "ld_wide.hpp"
 
 #ifndef LD_STEPS_PER_LAUNCH
 #define LD_STEPS_PER_LAUNCH 64
@@ -224,10 +225,64 @@ void keep_plan(const ld_mlp_spec& spec, int lanes, int64_t* in_lds, int64_t* in_
     *streamed = total - *in_lds - *in_registers;
 }
 
+// WidePlan (ld_wide.hpp) at run time: whether the spec's workgroups of 64 drones run fly_wide_kernel -- every gene word of
+// the block on chip, LD_WIDE_REG_WORDS per wavefront in registers and the rest in LDS -- and how many words go where.
+// (The shipped specs' accounting comes from the kernels' own compile-time plans; tests/test_host.py holds this against it.)
+bool wide_plan(const ld_mlp_spec& spec, int64_t* in_lds, int64_t* in_registers)
+{
+    constexpr int L = 8;
+    if (ld_mlp_words_per_drone(&spec) > 512) return false;
+    int dims[LD_MAX_HIDDEN_LAYERS + 2];
+    dims[0] = LD_N_INPUTS;
+    for (int i = 0; i < spec.n_hidden; ++i) dims[i + 1] = spec.hidden[i];
+    dims[spec.n_hidden + 1] = LD_N_OUTPUTS;
+    const int layers = spec.n_hidden + 1;
+    int64_t len[L], total = 0, rows = 0;
+    for (int k = 0; k < L; ++k) {
+        len[k] = 0;
+        int64_t offset = 0;
+        for (int l = 0; l < layers; ++l) {
+            const int64_t row0 = (int64_t)k * dims[l + 1] / L, row1 = (int64_t)(k + 1) * dims[l + 1] / L, stride = dims[l] + 1;
+            if (row1 > row0) len[k] += (offset + row1 * stride + 3) / 4 - (offset + row0 * stride) / 4;
+            offset += (int64_t)dims[l + 1] * stride;
+        }
+        total += len[k];
+    }
+    for (int l = 0; l < layers; ++l) rows += dims[l + 1];
+    const int64_t keep_words = (int64_t)LD_WIDE_KEEP_KIB * 1024 / (64 * 16);
+    int64_t lds = 0, regs = 0;
+    for (int k = 0; k < L; ++k) {
+        const int64_t first = LD_WIDE_REG_WORDS < len[k] ? LD_WIDE_REG_WORDS : len[k];
+        int64_t keep = total ? len[k] * keep_words / total : 0;
+        keep = keep < len[k] - first ? keep : len[k] - first;
+        if (len[k] - first - keep > 0) return false;             // a word would have to be loaded every timestep
+        lds += keep;
+        regs += first;
+    }
+    const int64_t lds_bytes = (lds + LD_WIDE_KEEP_DEPTH) * 64 * 16 + (rows + 6) * 64 * 4 +
+                              (LD_MAX_COINS * LD_COIN_STRIDE + LD_MAX_WALLS * LD_WALL_STRIDE) * 4;
+    if (lds_bytes > 160 * 1024) return false;
+    if (in_lds) *in_lds = lds;
+    if (in_registers) *in_registers = regs;
+    return true;
+}
+
+// (ld_debug_lds_keep(2) asks for the kernels that came before: workgroups of 32 drones without pairing, of 64 without fly_wide_kernel)
+bool flies_wide(const ld_mlp_spec* spec, int32_t n_steps)
+{
+    return keeps_genes(spec, n_steps) && (keep_bit(n_steps) & 0x200) == 0 && wide_plan(*spec, nullptr, nullptr);
+}
+
 int auto_waves_per_block(const ld_mlp_spec* spec, int64_t n, int32_t n_steps)
 {
     const int64_t blocks = (n + 63) / 64;
     if (keeps_genes(spec, n_steps)) {
+        // Where the whole net fits on chip for 64 drones (fly_wide_kernel, ld_wide.hpp) a workgroup flies twice the drones of
+        // fly_pair_kernel's in 1.2 x its time per timestep: us per timestep, 64 / 32 drones per workgroup (scripts/exp_wide.py):
+        // 32-32 x 65 536 10.0 / 16.5, x 16 384 2.53 / 4.17, x 8 192 (half the CUs without a workgroup of 64) 2.49 / 2.10; 64 x 65 536
+        // 9.9 / 17.1, x 8 192 2.48 / 2.20; 24-24 8.0 / 18.2, x 8 192 2.01 / 2.31, x 1 024 1.98 / 2.29; 16-16 6.3 / 13.3, x 1 024 1.57 / 1.67;
+        // 32: 5.9 / 13.5, x 1 024 1.46 / 1.68; 10-10 5.5 / 8.8, x 1 024 1.38 / 1.80.
+        if (flies_wide(spec, n_steps) && (blocks >= 256 || ld_mlp_words_per_drone(spec) <= 300)) return 8;
         // A workgroup of 8 wavefronts keeps 136 KiB of its drones' genes in LDS, holds 12-14 more words per wavefront in
         // registers, and has its CU to itself, so 256 workgroups are resident at a time and what they STREAM per timestep
         // should fit the L2s (32 MB): then the stream never reaches the Infinity Cache fabric and a timestep takes what its
@@ -675,6 +730,12 @@ int ld_version(void) { return LD_ABI_VERSION; }
 int ld_debug_force_generic(int on) { return g_force_generic.exchange(on ? 1 : 0); }
 
 int ld_debug_lds_keep(int mode) { return g_lds_keep.exchange(mode < 0 ? -1 : mode > 2 ? 1 : mode); }
+int ld_debug_wide_plan(const ld_mlp_spec* spec, int64_t* lds_words, int64_t* register_words)
+{
+    const int rc = check_spec(spec);
+    if (rc) return rc;
+    return wide_plan(*spec, lds_words, register_words) ? 1 : 0;
+}
 
 int ld_register_specialisation_f32(const ld_mlp_spec* spec, ld_fly_steps_f32_fn fly_steps, ld_mlp_forward_f32_fn mlp_forward,
                                    ld_fly_resident_f32_fn fly_resident)
@@ -782,6 +843,11 @@ int ld_fly_steps_kept_words_f32(const ld_mlp_spec* spec, int32_t waves_per_block
             return keep_words_##TAG(waves_per_block, keep >> 9, lds_words, register_words, streamed_words);
         LD_FOR_EACH_UNROLLED(X)
 #undef X
+        if (waves_per_block == 8 && flies_wide(spec, n_steps)) {
+            *streamed_words = 0;
+            wide_plan(*spec, lds_words, register_words);
+            return LD_OK;
+        }
         keep_plan(*spec, lanes, lds_words, register_words, streamed_words);
     }
     return LD_OK;

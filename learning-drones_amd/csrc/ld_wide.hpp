@@ -26,7 +26,7 @@
 
 // Gene words per wavefront held in registers (the rest of a wavefront's words is kept in LDS).
 #ifndef LD_WIDE_REG_WORDS
-#define LD_WIDE_REG_WORDS 37
+#define LD_WIDE_REG_WORDS 40
 #endif
 // KiB of LDS the plan may fill with gene words: an upper bound for its bookkeeping only -- a wavefront's share is
 // proportional to its stream, it takes what its registers leave and never more, and WidePlan::fits checks what is really used
@@ -165,39 +165,41 @@ fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __rest
     split_barrier();
 
     GeneWord<Real> kring[KD];
+#ifdef LD_DIAG_STAMPS
+    unsigned long long diag_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int32_t t = 0; t < n_steps; ++t) {
         if (t > 0 && __all(dead)) break;                      // every wavefront of the workgroup sees the same 64 drones
+        LD_STAMP(st_top)
 #pragma unroll
         for (int j = 0; j < KD; ++j) kring[j] = my_kept[j * 64];          // (a wavefront with fewer kept words reads rows it never uses)
         // ---- the controller's output of the last step acts now (flight/__init__.py:89; none after a crash), and the
-        // angles' sin / cos come from the wavefronts that computed them beside the output layer
-        Real sc[6];
-#pragma unroll
-        for (int k = 0; k < LD_N_OUTPUTS; ++k) {
-            const Real u = xch[WP::kThrustRow + k][lane];
-            d.u[k] = dead ? d.u[k] : u;
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) sc[k] = xch[WP::kScRow + k][lane];
-        // ---- flight/__init__.py:41-52, :79
-        int32_t r = reward + ep.reward_time;
-        int32_t nc = ncoll;
+        // angles' sin / cos come from the wavefronts that computed them beside the output layer.  A drone that crashed
+        // earlier keeps the state it crashed with (:80-87): its lane sits out the step (the other kernels commit by selects,
+        // to keep their gene loads in flight across the step; here nothing is in flight, and a masked lane costs no copy
+        // of the state)
         Real c[LD_COIN_STRIDE];
-        if (current_coin<Real>(ep, tab.coins, nc, c)) {
-            if (coin_distance<Real>(c, d.s) < c[3]) { r += (int32_t)c[4]; nc += 1; }
+        if (!dead) {
+            Real sc[6];
+#pragma unroll
+            for (int k = 0; k < LD_N_OUTPUTS; ++k) d.u[k] = xch[WP::kThrustRow + k][lane];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sc[k] = xch[WP::kScRow + k][lane];
+            // ---- flight/__init__.py:41-52, :79
+            int32_t r = reward + ep.reward_time;
+            if (current_coin<Real>(ep, tab.coins, ncoll, c)) {
+                if (coin_distance<Real>(c, d.s) < c[3]) { r += (int32_t)c[4]; ncoll += 1; }
+            }
+            dead = measure<Real, false>(sim, ep, tab.walls, d, r, sc);
+            reward = r;
+            flight_time += 1;
         }
-        DroneRegs<Real> e = d;
-        const bool crashed = measure<Real, false>(sim, ep, tab.walls, e, r, sc);
-        const bool was_dead = dead;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) d.s[k] = was_dead ? d.s[k] : e.s[k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) d.acc[k] = was_dead ? d.acc[k] : e.acc[k];
-        reward = was_dead ? reward : r;
-        ncoll = was_dead ? ncoll : nc;
-        flight_time += was_dead ? 0 : 1;
-        dead = was_dead || crashed;
         current_coin<Real>(ep, tab.coins, ncoll, c);
+        LD_STAMP(st_phys)
+        LD_STAMP_ADD(0, st_top, st_phys)
+#ifdef LD_DIAG_STAMPS
+        unsigned long long st_prev = st_phys;
+#endif
 
         // ---- controller on the post-step state (evolve/brain.py:41-54); frozen lanes compute on their frozen state and
         // the result is discarded above
@@ -246,7 +248,14 @@ fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __rest
                 for (int j = r0; j < r1; ++j) xch[Plan::xch_row(layer) + j][lane] = out[j - r0];
                 // beside the output layer: sin / cos of the angles the next step starts from
                 if constexpr (last && WP::side_job(K) >= 0 && WP::side_job(K) < 3) angles_job(WP::side_job(K));
+                LD_STAMP(st_work)
+                LD_STAMP_ADD(1 + 2 * layer, st_prev, st_work)
                 split_barrier();
+                LD_STAMP(st_bar)
+                LD_STAMP_ADD(2 + 2 * layer, st_work, st_bar)
+#ifdef LD_DIAG_STAMPS
+                st_prev = st_bar;
+#endif
                 if constexpr (!last) {
 #pragma unroll
                     for (int j = 0; j < n_out; ++j) act[j] = xch[Plan::xch_row(layer) + j][lane];
@@ -254,6 +263,10 @@ fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __rest
             });
         });
     }
+#ifdef LD_DIAG_STAMPS
+    if (lane == 0 && blockIdx.x == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&ld_diag_cycles[wave][k], diag_sum[k]);
+#endif
     if (!dead0 && wave == 0) {
         // the last step's output, as the next launch (or the drone's record) finds it
 #pragma unroll

@@ -352,6 +352,11 @@ class Population:
         return {"steps_per_launch": k.value, "waves_per_block": w.value, "launches": m.value, "tile_drones": tile.value,
                 "lds_words": lds, "register_words": regs, "streamed_words": streamed}
 
+    def flies_wide(self) -> bool:
+        """Whether this population's workgroups of 64 drones (waves_per_block 8, launches that keep their genes) run
+        fly_wide_kernel: every gene word on chip, the angles' sin / cos computed beside the output layer (csrc/ld_wide.hpp)."""
+        return self.precision == "f32" and _native.lib().ld_debug_wide_plan(C.byref(self.spec), None, None) == 1
+
     def kept_words(self, waves_per_block: int, n_steps: int):
         """Gene words per drone a launch of `n_steps` timesteps in the geometry `waves_per_block` (keeps in LDS, holds in
         registers, loads from memory every timestep) (ld_fly_steps_kept_words_f32)."""

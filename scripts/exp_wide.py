@@ -6,7 +6,9 @@ import torch
 from bench import make_genomes
 from learning_drones_amd import Population, _native
 from learning_drones_amd.params import coin_chain_reference
+import os
 lib = _native.lib()
+tag = os.path.basename(os.environ.get("LD_DRONES_LIB", "shipped"))
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 def timed(fn, reps=4):
     fn(); torch.cuda.synchronize()
@@ -21,7 +23,7 @@ for hidden in specs:
     for n in sizes:
         pop = Population(n, hidden, coins=coin_chain_reference(3), specialise=False)
         pop.set_genomes(make_genomes(torch, n, hidden, pop.device, 0))
-        row = {"hidden": hidden, "n": n}
+        row = {"lib": tag, "hidden": hidden, "n": n}
         ref = None
         # (mode, waves_per_block): nothing kept; the paired kernel; the unwide 64-drone workgroups; the wide kernel
         for mode, waves, name in ((0, 0, "nokeep"), (1, 16, "pair32"), (2, 8, "split64"), (1, 8, "wide64")):

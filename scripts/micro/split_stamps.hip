@@ -12,6 +12,7 @@
 // copies in a namespace of their own.
 #define ld ld_stamped
 #include "ld_split.hpp"
+#include "ld_wide.hpp"
 
 #include <cstdio>
 #include <cstdlib>
@@ -41,7 +42,10 @@ int run(int64_t n, int steps, int reps)
         CHECK(hipMemcpyToSymbol(HIP_SYMBOL(ld::ld_diag_cycles), zero, sizeof zero));
         if (ld_population_reset_f32(fstate, istate, n, nullptr, nullptr)) return 1;
         CHECK(hipEventRecord(e0, nullptr));
-        if (ld::launch_fly_split<float, false, 8, S, Keep, (Keep == 0 ? 0 : S == 1 ? LD_SPLIT_REG_WORDS_64 : S == 2 ? LD_SPLIT_REG_WORDS_32 : S == 3 ? LD_SPLIT_REG_WORDS_48 : 0), 32, 32>(&sim, &ep, coins, nullptr, genomes, fstate, istate, n, 0, n, steps, nullptr)) return 1;
+        if constexpr (S == 8) {
+            if (ld::launch_fly_wide<LD_WIDE_KEEP_KIB, LD_WIDE_REG_WORDS, 32, 32>(&sim, &ep, coins, nullptr, genomes, fstate, istate, n, 0, n, steps, nullptr)) return 1;
+        } else
+        if (ld::launch_fly_split<float, false, 8, S == 8 ? 1 : S, Keep, (Keep == 0 ? 0 : S == 1 ? LD_SPLIT_REG_WORDS_64 : S == 2 ? LD_SPLIT_REG_WORDS_32 : S == 3 ? LD_SPLIT_REG_WORDS_48 : 0), 32, 32>(&sim, &ep, coins, nullptr, genomes, fstate, istate, n, 0, n, steps, nullptr)) return 1;
         CHECK(hipEventRecord(e1, nullptr));
         CHECK(hipDeviceSynchronize());
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -66,6 +70,7 @@ int main(int argc, char** argv)
 {
     const int64_t n = argc > 1 ? std::atoll(argv[1]) : 16384;
     const int S = argc > 2 ? std::atoi(argv[2]) : 1, keep = argc > 3 ? std::atoi(argv[3]) : 136;
+    if (S == 8) return run<8, 136>(n, argc > 4 ? std::atoi(argv[4]) : 64, 3);      // fly_wide_kernel (ld_wide.hpp)
     if (S == 1) return keep ? run<1, 136>(n, 64, 3) : run<1, 0>(n, 64, 3);
     if (S == 2) return keep ? run<2, 136>(n, 64, 3) : run<2, 0>(n, 64, 3);
     if (S == 3) return run<3, 136>(n, 64, 3);

@@ -246,8 +246,8 @@ def _replicated(hidden, m, n, seed):
 
 def test_full_size_config4_shard(Population, torch):
     """One GPU's share of BASELINE config 4: 32 768 drones x 4 000 steps, 15-32-32-4, 3-coin chain (the
-    launch geometry this shard gets: 512 timesteps per launch, all 32 768 drones in one launch, two workgroups of 8 wavefronts per
-    genome block, both halves of every wavefront summing rows, all of its 32 drones' genes held in registers (424 words) and LDS (12) for the launch).  Size-independent
+    launch geometry this shard gets: 512 timesteps per launch, all 32 768 drones in one launch, one workgroup of 8 wavefronts per
+    genome block (fly_wide_kernel), all of its 64 drones' genes held in registers (320 words per drone) and LDS (108) for the launch).  Size-independent
     properties: genomes replicated from a 256-drone population under a random permutation give the
     permuted small-population results bit for bit; a re-run is bit-identical; one launch per timestep
     and the resident engine give the same records."""
@@ -261,13 +261,13 @@ def test_full_size_config4_shard(Population, torch):
     pop = Population(n, hidden, coins=coins)
     pop.set_genomes(torch.as_tensor(genes_m, dtype=torch.float32, device="cuda")[torch.as_tensor(src, device="cuda")])
     geo = pop.rollout_geometry(T)
-    assert geo == {"steps_per_launch": 512, "waves_per_block": 16, "launches": 8, "tile_drones": 32768, "lds_words": 12, "register_words": 424, "streamed_words": 0}
+    assert geo == {"steps_per_launch": 512, "waves_per_block": 8, "launches": 8, "tile_drones": 32768, "lds_words": 108, "register_words": 320, "streamed_words": 0}
     pop.fly(T)
     got = pop.results()
     for f in ("reward", "flight_time", "coins", "crashed", "distance_to_coin"):
         assert np.array_equal(got[f], want[f][src]), f
     rec = pop.records.clone()
-    for kw in (dict(steps_per_launch=1), dict(tile_drones=16384, waves_per_block=8), dict(tile_drones=4096 + 64, waves_per_block=2),
+    for kw in (dict(steps_per_launch=1), dict(tile_drones=16384, waves_per_block=16), dict(tile_drones=4096 + 64, waves_per_block=2),
                dict(waves_per_block=11), dict(engine="resident"), {}):
         pop.reset()
         pop.fly(T, **kw)
@@ -641,7 +641,7 @@ def test_kept_genes_are_bit_identical_on_a_ragged_population(Population, torch, 
     pop = Population(n, hidden, walls=walls, coins=coin_chain_reference(2))
     pop.set_genomes(torch.as_tensor(genes_m, dtype=torch.float32, device="cuda")[torch.as_tensor(src, device="cuda")])
     geo = pop.rollout_geometry(T)
-    assert geo["tile_drones"] == n and geo["waves_per_block"] == 16 and geo["lds_words"] + geo["register_words"] == 436 and geo["streamed_words"] == 0
+    assert geo["tile_drones"] == n and geo["waves_per_block"] == 8 and geo["lds_words"] + geo["register_words"] == 428 and geo["streamed_words"] == 0   # fly_wide_kernel
     assert lib.ld_debug_lds_keep(0) == -1
     try:
         assert pop.rollout_geometry(T)["tile_drones"] == 16384 and pop.rollout_geometry(T)["lds_words"] == 0
@@ -651,9 +651,10 @@ def test_kept_genes_are_bit_identical_on_a_ragged_population(Population, torch, 
     want = (pop.fstate.clone(), pop.istate.clone(), pop.records.clone())
     crashed = (want[1][2] & 1).bool()
     assert crashed.any() and not crashed.all() and int(want[1][1].max()) >= 1
-    for rep, kw in enumerate(({}, {}, dict(waves_per_block=8), dict(waves_per_block=11), dict(waves_per_block=32),
+    for rep, kw in enumerate(({}, {}, dict(waves_per_block=16), dict(waves_per_block=11), dict(waves_per_block=32),
                               dict(waves_per_block=11, tile_drones=12288), dict(steps_per_launch=9), dict(steps_per_launch=7),
-                              dict(unpaired=True))):
+                              dict(waves_per_block=16, steps_per_launch=9), dict(unpaired=True, waves_per_block=16),
+                              dict(unpaired=True, waves_per_block=8))):
         pop.reset()
         if kw.pop("unpaired", False):                                     # the same workgroups of 32 drones without the paired halves
             assert lib.ld_debug_lds_keep(2) == -1

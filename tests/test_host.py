@@ -181,26 +181,38 @@ def test_argument_validation_without_gpu(lib):
     k, w, m, tile = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
     geo = lambda h, n, T: (lib.ld_fly_rollout_geometry_f32(C.byref(MlpSpec.from_hidden(h)), n, T, C.byref(k), C.byref(w), C.byref(m),
                                                             C.byref(tile)), k.value, w.value, m.value, tile.value)
-    # nets of up to 512 gene words that split evenly over 8 wavefronts keep 136 KiB of genes per workgroup in LDS: no tiles,
-    # workgroups of 8 wavefronts, as many per block as keep the resident workgroups' stream within the L2s (32-32: two; 16-16: one,
-    # unless the launch is too small to give every CU a workgroup of 64 drones)
-    # (and 512 timesteps per launch instead of 64: the genes are loaded once per launch)
-    assert geo((32, 32), 65536, 2000) == (OK, 512, 16, 4, 65536) and geo((32, 32), 8192, 2000) == (OK, 512, 16, 4, 8192)
-    assert geo((32, 32), 32768, 4000) == (OK, 512, 16, 8, 32768)          # config 4 shard
-    assert geo((32, 32), 16384, 2000) == (OK, 512, 16, 4, 16384) and geo((32, 32), 1024, 2000) == (OK, 512, 16, 4, 1024)
-    assert geo((16, 16), 65536, 2000) == (OK, 512, 8, 4, 65536) and geo((16, 16), 1024, 2000) == (OK, 512, 16, 4, 1024)   # config 2
+    # nets of up to 512 gene words keep their genes on chip for the launch: no tiles, 512 timesteps per launch (the genes are
+    # loaded once per launch), workgroups of 8 wavefronts -- of 64 drones (fly_wide_kernel: every gene on chip) where the launch
+    # gives every CU one or the net is small (<= 300 words), of 32 drones (fly_pair_kernel) otherwise
+    assert geo((32, 32), 65536, 2000) == (OK, 512, 8, 4, 65536) and geo((32, 32), 8192, 2000) == (OK, 512, 16, 4, 8192)
+    assert geo((32, 32), 32768, 4000) == (OK, 512, 8, 8, 32768)           # config 4 shard
+    assert geo((32, 32), 16384, 2000) == (OK, 512, 8, 4, 16384) and geo((32, 32), 1024, 2000) == (OK, 512, 16, 4, 1024)
+    assert geo((16, 16), 65536, 2000) == (OK, 512, 8, 4, 65536) and geo((16, 16), 1024, 2000) == (OK, 512, 8, 4, 1024)   # config 2
+    assert geo((64,), 8192, 100) == (OK, 512, 16, 1, 8192) and geo((64,), 65536, 100) == (OK, 512, 8, 1, 65536) and geo((24, 24), 8192, 100)[2] == 8
     in_lds, in_regs, streamed = C.c_int64(), C.c_int64(), C.c_int64()
     words = lambda h, w, steps: (lib.ld_fly_steps_kept_words_f32(C.byref(MlpSpec.from_hidden(h)), w, steps, C.byref(in_lds), C.byref(in_regs),
                                                                  C.byref(streamed)), in_lds.value, in_regs.value, streamed.value)
     # (gene words per drone kept in LDS, held in registers, loaded every timestep): 32-32 has 428 (three words straddle two
     # wavefronts' rows and are loaded by both)
-    assert words((32, 32), 8, 64)[1:] == (132, 96, 200) and words((32, 32), 11, 64)[1:] == (176, 96, 156)
+    assert words((32, 32), 11, 64)[1:] == (176, 96, 156)
+    # workgroups of 64 drones (fly_wide_kernel): 40 words per wavefront in registers, the rest in LDS, nothing loaded per timestep
+    assert words((32, 32), 8, 64)[1:] == (108, 320, 0) and words((64,), 8, 64)[1:] == (36, 288, 0) and words((24, 24), 8, 64)[1:] == (0, 280, 0)
+    assert words((16, 16), 8, 64)[1:] == (0, 156, 0) and words((10, 10), 8, 64)[1:] == (0, 88, 0)
+    # ... and the run-time restatement of that plan, which the policy asks for specs specialised at run time, agrees with the kernels' own
+    wide_lds, wide_regs = C.c_int64(), C.c_int64()
+    for h in ((32, 32), (16, 16), (64,), (24, 24), (32,), (16,), (10, 10), (8, 8), (8, 10)):
+        assert lib.ld_debug_wide_plan(C.byref(MlpSpec.from_hidden(h)), C.byref(wide_lds), C.byref(wide_regs)) == 1
+        assert words(h, 8, 64)[1:] == (wide_lds.value, wide_regs.value, 0), h
+    for h in ((48, 48), (64, 64), (32, 32, 32), (64, 64, 64)):              # more gene words than a CU holds for 64 drones
+        assert lib.ld_debug_wide_plan(C.byref(MlpSpec.from_hidden(h)), C.byref(wide_lds), C.byref(wide_regs)) == 0
+    assert lib.ld_debug_wide_plan(None, None, None) == NULL
     # workgroups of 32 drones pair the halves of a wavefront (ld_pair.hpp): a stream position is two gene words, 32 positions per
     # wavefront stay in registers, LDS keeps the rest: everything on chip (436 = 425 + the words two rows' blocks share)
     assert words((32, 32), 16, 64)[1:] == (12, 424, 0) and words((16, 16), 16, 64)[1:] == (0, 164, 0) and words((64,), 16, 64)[1:] == (100, 224, 0)
     assert words((24, 24), 16, 64)[1:] == (268, 12, 0)                      # 24 rows: no pairing, the unpaired kernel's plan
-    assert lib.ld_debug_lds_keep(2) == -1 and words((32, 32), 16, 64)[1:] == (268, 112, 48) and lib.ld_debug_lds_keep(-1) == 2   # (the unpaired kernel of the same geometry)
-    assert words((32, 32), 32, 64)[1:] == (428, 0, 0) and words((16, 16), 8, 64)[1:] == (132, 24, 0)   # everything on chip
+    assert lib.ld_debug_lds_keep(2) == -1 and words((32, 32), 16, 64)[1:] == (268, 112, 48) and words((32, 32), 8, 64)[1:] == (132, 96, 200)   # (the kernels of before, same geometries)
+    assert geo((32, 32), 65536, 2000) == (OK, 512, 16, 4, 65536) and lib.ld_debug_lds_keep(-1) == 2
+    assert words((32, 32), 32, 64)[1:] == (428, 0, 0)                       # everything on chip
     assert words((32, 32), 16, 4)[1:] == (0, 0, 425) and words((32, 32), 4, 64)[1:] == (0, 0, 425)   # short launches and other geometries keep nothing
     assert words((64, 64, 64), 8, 64)[1:] == (0, 0, 2401) and words((32, 32), 3, 64)[0] == SIZE
     # ... and without the kept genes (ld_debug_lds_keep(0)): tiles of ~112 MB of genes that the Infinity Cache holds
@@ -211,7 +223,7 @@ def test_argument_validation_without_gpu(lib):
     assert geo((64, 64, 64), 131072, 4000) == (OK, 64, 8, 63, 131072)     # 38 KB of genes per drone: a tile could not fill the chip; two workgroups of 4
     assert geo((64, 64, 64), 8192, 100) == (OK, 64, 8, 2, 8192) and geo((12,), 1000, 50) == (OK, 64, 1, 1, 1000)   # run-time spec: one wavefront per block, 64 timesteps per launch
     assert geo((10, 10), 65536, 2000) == (OK, 512, 8, 4, 65536)           # the reference's own controller: 79 gene words, all of them kept on chip
-    assert geo((10, 10), 1024, 2000)[2] == 16 and geo((8, 8), 1024, 2000)[2] == 16
+    assert geo((10, 10), 1024, 2000)[2] == 8 and geo((8, 8), 1024, 2000)[2] == 8
     assert geo((10, 10), 1048576, 100)[4] == 1048576                      # launches that keep their genes are not tiled
     assert lib.ld_debug_lds_keep(0) == -1
     assert geo((10, 10), 65536, 2000) == (OK, 64, 2, 32, 65536)           # nothing kept: 82 MB fits the Infinity Cache as it is; 10 rows split evenly over 2 wavefronts only
@@ -259,7 +271,9 @@ def test_runtime_specialisation_builds_and_registers(lib):
     k, w, m = C.c_int32(), C.c_int32(), C.c_int32()
     tile = C.c_int64()
     assert lib.ld_fly_rollout_geometry_f32(C.byref(spec), 8192, 2000, C.byref(k), C.byref(w), C.byref(m), C.byref(tile)) == 0
-    assert (k.value, w.value, m.value, tile.value) == (512, 16, 4, 8192)                   # the specialised spec takes the multi-step, gene-keeping geometry (workgroups of 32 drones: 8 192 drones are 128 blocks)
+    assert (k.value, w.value, m.value, tile.value) == (512, 8, 4, 8192)                    # the specialised spec takes the multi-step, gene-keeping geometry (a small net: workgroups of 64 drones, fly_wide_kernel)
+    wide_lds, wide_regs = C.c_int64(), C.c_int64()
+    assert lib.ld_debug_wide_plan(C.byref(spec), C.byref(wide_lds), C.byref(wide_regs)) == 1 and (wide_lds.value, wide_regs.value) == (0, 92)
     assert lib.ld_debug_force_generic(1) == 0 and lib.ld_has_specialisation_f32(C.byref(spec)) == 0
     assert lib.ld_debug_force_generic(0) == 1
     # the entry points validate like the built-in ones (n == 0 is a no-op, no kernel is launched without a GPU)

@@ -275,8 +275,8 @@ def main():
         wide = kept > 0 and streamed == 0 and geo["waves_per_block"] == 8 and pop.local.flies_wide()
         if wide:
             # the layer outputs (and the angles' sin / cos) that cross wavefronts through LDS: every wavefront reads every hidden
-            # layer's outputs, four read the last hidden layer's, every one the 4 thrusts and the 6 sin / cos values; written once
-            xch_words = 8 * sum(hidden[:-1]) + 4 * hidden[-1] + 8 * 10 + sum(hidden) + 4 + 6
+            # layer's outputs, four read the last hidden layer's, every one the 4 thrusts, the 6 sin / cos values, 1 / cos(pitch) and the coin flag; written once
+            xch_words = 8 * sum(hidden[:-1]) + 4 * hidden[-1] + 8 * 12 + sum(hidden) + 4 + 8
             lds_bytes += drones_per_launch_avg * steps_per_launch_avg * 4 * xch_words
             levels["lds"]["bytes_per_launch"] = lds_bytes
             levels["lds"]["achieved"] = lds_bytes / launch_s / 1e9

@@ -211,7 +211,6 @@ void keep_plan(const ld_mlp_spec& spec, int lanes, int64_t* in_lds, int64_t* in_
             if (row1 > row0) len[k] += (offset + row1 * stride + 3) / 4 - (offset + row0 * stride) / 4;
             offset += (int64_t)dims[l + 1] * stride;
         }
-        total += len[k];
     }
     const int64_t keep_words = (int64_t)LD_SPLIT_KEEP_KIB * 1024 / (lanes * 16);
     const int64_t reg_words = lanes == 64 ? LD_SPLIT_REG_WORDS_64 : lanes == 48 ? LD_SPLIT_REG_WORDS_48 : lanes == 32 ? LD_SPLIT_REG_WORDS_32 : 0;
@@ -237,7 +236,7 @@ bool wide_plan(const ld_mlp_spec& spec, int64_t* in_lds, int64_t* in_registers)
     for (int i = 0; i < spec.n_hidden; ++i) dims[i + 1] = spec.hidden[i];
     dims[spec.n_hidden + 1] = LD_N_OUTPUTS;
     const int layers = spec.n_hidden + 1;
-    int64_t len[L], total = 0, rows = 0;
+    int64_t len[L], rows = 0;
     for (int k = 0; k < L; ++k) {
         len[k] = 0;
         int64_t offset = 0;
@@ -246,20 +245,15 @@ bool wide_plan(const ld_mlp_spec& spec, int64_t* in_lds, int64_t* in_registers)
             if (row1 > row0) len[k] += (offset + row1 * stride + 3) / 4 - (offset + row0 * stride) / 4;
             offset += (int64_t)dims[l + 1] * stride;
         }
-        total += len[k];
     }
     for (int l = 0; l < layers; ++l) rows += dims[l + 1];
-    const int64_t keep_words = (int64_t)LD_WIDE_KEEP_KIB * 1024 / (64 * 16);
     int64_t lds = 0, regs = 0;
     for (int k = 0; k < L; ++k) {
-        const int64_t first = LD_WIDE_REG_WORDS < len[k] ? LD_WIDE_REG_WORDS : len[k];
-        int64_t keep = total ? len[k] * keep_words / total : 0;
-        keep = keep < len[k] - first ? keep : len[k] - first;
-        if (len[k] - first - keep > 0) return false;             // a word would have to be loaded every timestep
-        lds += keep;
-        regs += first;
+        const int64_t held = LD_WIDE_REG_WORDS < len[k] ? LD_WIDE_REG_WORDS : len[k];
+        regs += held;
+        lds += len[k] - held;
     }
-    const int64_t lds_bytes = (lds + LD_WIDE_KEEP_DEPTH) * 64 * 16 + (rows + 6) * 64 * 4 +
+    const int64_t lds_bytes = (lds + LD_WIDE_KEEP_DEPTH) * 64 * 16 + (rows + 8) * 64 * 4 +
                               (LD_MAX_COINS * LD_COIN_STRIDE + LD_MAX_WALLS * LD_WALL_STRIDE) * 4;
     if (lds_bytes > 160 * 1024) return false;
     if (in_lds) *in_lds = lds;
@@ -278,11 +272,11 @@ int auto_waves_per_block(const ld_mlp_spec* spec, int64_t n, int32_t n_steps)
     const int64_t blocks = (n + 63) / 64;
     if (keeps_genes(spec, n_steps)) {
         // Where the whole net fits on chip for 64 drones (fly_wide_kernel, ld_wide.hpp) a workgroup flies twice the drones of
-        // fly_pair_kernel's in 1.2 x its time per timestep: us per timestep, 64 / 32 drones per workgroup (scripts/exp_wide.py):
-        // 32-32 x 65 536 10.0 / 16.5, x 16 384 2.53 / 4.17, x 8 192 (half the CUs without a workgroup of 64) 2.49 / 2.10; 64 x 65 536
-        // 9.9 / 17.1, x 8 192 2.48 / 2.20; 24-24 8.0 / 18.2, x 8 192 2.01 / 2.31, x 1 024 1.98 / 2.29; 16-16 6.3 / 13.3, x 1 024 1.57 / 1.67;
-        // 32: 5.9 / 13.5, x 1 024 1.46 / 1.68; 10-10 5.5 / 8.8, x 1 024 1.38 / 1.80.
-        if (flies_wide(spec, n_steps) && (blocks >= 256 || ld_mlp_words_per_drone(spec) <= 300)) return 8;
+        // fly_pair_kernel's in less than its time per timestep: us per timestep, 64 / 32 drones per workgroup (scripts/exp_wide.py,
+        // gpurun_out -> profiles/r03_wide.json): 32-32 x 65 536 7.6 / 16.4, x 8 192 (half the CUs without a workgroup of 64) 1.89 / 2.07,
+        // x 1 024 1.88 / 2.06; 64 x 65 536 6.9 / 17.3, x 1 024 1.70 / 2.17; 24-24 5.9 / 18.0, x 1 024 1.45 / 2.26; 16-16 4.6 / 13.4,
+        // x 1 024 1.15 / 1.68; 32: 4.5 / 13.7, x 1 024 1.12 / 1.69; 10-10 4.3 / 8.7, x 1 024 1.07 / 1.75.
+        if (flies_wide(spec, n_steps)) return 8;
         // A workgroup of 8 wavefronts keeps 136 KiB of its drones' genes in LDS, holds 12-14 more words per wavefront in
         // registers, and has its CU to itself, so 256 workgroups are resident at a time and what they STREAM per timestep
         // should fit the L2s (32 MB): then the stream never reaches the Infinity Cache fabric and a timestep takes what its

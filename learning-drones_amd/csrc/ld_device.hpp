@@ -82,8 +82,10 @@ template <typename Real> inline EpT<Real> make_ep(const ld_episode_params& e)
 //   a_rot = Tr(roll, pitch) * (([L,M,N] + M_p) * 1/I)
 // ---------------------------------------------------------------------------------------------
 // sc = sin / cos of roll, pitch, yaw: sr, cr, sp, cp, sy, cy
+// inv_cos_pitch: 1 / cp computed elsewhere (the same IEEE division of the same value), or nullptr
 template <typename Real, typename Sim>
-__device__ __forceinline__ void accel_closed_sc(const Sim& p, const Real sc[6], const Real u[4], Real lin[3], Real rot[3])
+__device__ __forceinline__ void accel_closed_sc(const Sim& p, const Real sc[6], const Real u[4], Real lin[3], Real rot[3],
+                                                const Real* inv_cos_pitch = nullptr)
 {
     const Real sr = sc[0], cr = sc[1], sp = sc[2], cp = sc[3], sy = sc[4], cy = sc[5];
     const Real cf = (Real)p.coef_force, cm = (Real)p.coef_moment, r = (Real)p.radius_motor;
@@ -101,7 +103,7 @@ __device__ __forceinline__ void accel_closed_sc(const Sim& p, const Real sc[6], 
     const Real b0 = (L + (Real)p.moments_payload[0]) * (Real)p.inv_inertia[0];
     const Real b1 = (M + (Real)p.moments_payload[1]) * (Real)p.inv_inertia[1];
     const Real b2 = (N + (Real)p.moments_payload[2]) * (Real)p.inv_inertia[2];
-    const Real inv_cp = (Real)1 / cp;
+    const Real inv_cp = inv_cos_pitch ? *inv_cos_pitch : (Real)1 / cp;
     const Real tp = sp * inv_cp;
     rot[0] = b0 + (sr * tp) * b1 + (cr * tp) * b2;
     rot[1] = cr * b1 - sr * b2;
@@ -283,16 +285,17 @@ template <typename Real> struct DroneRegs {
 // drone/drone.py:129-165 (+ build-defined wall boxes held in LDS).  Returns true if crashed;
 // `reward` receives the crash / instability terms.
 // `sc` (closed form only): sin / cos of the three angles computed elsewhere -- the resident kernel computes
-// them on three different lanes of the drone's group at once instead of three times on every lane.
+// them on three different lanes of the drone's group at once instead of three times on every lane; fly_wide_kernel on
+// three other wavefronts, together with `inv_cos_pitch` = 1 / cos(pitch).
 template <typename Real, bool Faithful, typename Sim, typename Ep>
 __device__ __forceinline__ bool measure(const Sim& sim, const Ep& ep,
                                         const Real* __restrict__ lds_walls, DroneRegs<Real>& d, int32_t& reward,
-                                        const Real* sc = nullptr)
+                                        const Real* sc = nullptr, const Real* inv_cos_pitch = nullptr)
 {
     Real lin[3], rot[3];
     const Real dt = (Real)sim.dt;
     if constexpr (!Faithful) {
-        if (sc) accel_closed_sc<Real, Sim>(sim, sc, d.u, lin, rot);
+        if (sc) accel_closed_sc<Real, Sim>(sim, sc, d.u, lin, rot, inv_cos_pitch);
         else accel_closed<Real, Sim>(sim, &d.s[6], d.u, lin, rot);
     } else {
         accelerations<Real, Faithful>(sim, &d.s[6], d.u, lin, rot);

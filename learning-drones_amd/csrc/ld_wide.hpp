@@ -4,20 +4,25 @@
 // its 8 wavefronts repeats per timestep: the rigid-body step with its three sincosf (two thirds of the vector instructions
 // a wavefront issues), for 32 drones per CU.  Here a workgroup of 8 wavefronts flies the 64 drones of ONE genome block, the
 // lane is the drone in every wavefront (no lane idles, no lane repeats another's rows), and
-//   - every gene word of the block stays on chip for the launch: RegWords per wavefront in registers, the rest in LDS
-//     (KeepPlanOf over SplitPlan<8>: wavefront k owns rows [k n_out / 8, (k + 1) n_out / 8) of every layer) -- nothing is
-//     loaded from memory inside the timestep loop;
+//   - every gene word of the block stays on chip for the launch: RegWords per wavefront in registers (the output layer's
+//     first: its one row per wavefront is the longest dependent chain of the timestep), the rest in LDS (WideSched over
+//     SplitPlan<8>: wavefront k owns rows [k n_out / 8, (k + 1) n_out / 8) of every layer) -- nothing is loaded from memory
+//     inside the timestep loop;
 //   - the timestep is rotated so that what does not depend on the controller's output runs BESIDE the controller: the
 //     sin / cos of the three Euler angles the NEXT rigid-body step needs are known as soon as this step's integrator has run,
 //     and three of the four wavefronts that have no row of the output layer compute one angle's pair each while the
 //     other four sum the output rows; the six values travel through LDS like a layer's outputs.  What is left of the
 //     rigid-body step on the path between the output layer and the first layer is the closed-form accelerations from those
-//     six values, the integrator, the crash / stability tests and the coin test (about 150 vector instructions instead
-//     of 350).
-// Per timestep and wavefront that is about 450 vector instructions for 64 drones, where the paired kernel issues 436 for 32.
-// Every neuron's sum still runs over its inputs in gene order on one lane, the six sin / cos values are the same function
-// of the same angles whichever wavefront computes them (as in the resident kernel): results are bit-identical to every other
-// engine.
+//     six values, the integrator, the crash / stability tests and the coin test (about 190 vector instructions instead
+//     of 390);
+//   - a wavefront's rows of a layer advance TOGETHER, one gene word of each row in turn (a row's words are taken in order,
+//     so every neuron's sum still runs over its inputs in gene order on one lane): up to four independent chains of fused
+//     multiply-adds per wavefront instead of one (a dependent v_fma_f32 issues every ~7 cycles, two wavefronts per SIMD
+//     fill 3.5 of them), and the layer's inputs are read from the exchange rows in LDS as the rows reach them, through a
+//     window of 16 registers instead of one register per input.
+// Per timestep and wavefront that is about 420 vector instructions for 64 drones, where the paired kernel issues 436 for 32.
+// The six sin / cos values are the same function of the same angles whichever wavefront computes them (as in the resident
+// kernel): results are bit-identical to every other engine.
 //
 // Reference semantics: flight/__init__.py:39-89, as fly_step_kernel.
 #pragma once
@@ -26,28 +31,116 @@
 
 // Gene words per wavefront held in registers (the rest of a wavefront's words is kept in LDS).
 #ifndef LD_WIDE_REG_WORDS
-#define LD_WIDE_REG_WORDS 40
-#endif
-// KiB of LDS the plan may fill with gene words: an upper bound for its bookkeeping only -- a wavefront's share is
-// proportional to its stream, it takes what its registers leave and never more, and WidePlan::fits checks what is really used
-#ifndef LD_WIDE_KEEP_KIB
-#define LD_WIDE_KEEP_KIB 192
+#define LD_WIDE_REG_WORDS 38
 #endif
 // kept words in flight from LDS per lane
 #ifndef LD_WIDE_KEEP_DEPTH
-#define LD_WIDE_KEEP_DEPTH 2
+#define LD_WIDE_KEEP_DEPTH 4
+#endif
+
+// what may cross the scheduling barrier behind every round of a layer (__builtin_amdgcn_sched_barrier's mask): nothing
+#ifndef LD_WIDE_SCHED_MASK
+#define LD_WIDE_SCHED_MASK 0
 #endif
 
 namespace ld {
 
-template <int KeepKiB, int RegWords, int... H> struct WidePlan {
+// Where every gene word of a wavefront lives and in which order a layer's words are consumed, worked out ONCE per
+// instantiation into tables (as KeepPlanOf, ld_split.hpp).  A wavefront's STREAM is the words of its rows, layer by layer
+// (SplitPlan<8>); a word that holds the end of one row and the start of the next is one stream position, consumed twice.
+//   class of a position: 1 = held in a register for the launch, 0 = kept in LDS.  RegWords registers per wavefront: the
+//   output layer's positions first, the rest spread evenly over the other positions (the LDS reads then alternate with
+//   register words, whose FMAs cover their latency).
+//   items of a layer: (row, position) pairs in the order the kernel consumes them -- round r takes the r-th word of every
+//   row of the wavefront in turn.  The LDS items of a wavefront are numbered in consumption order across the layers: the
+//   kernel keeps KD of them in flight.
+template <int RegWords, int... H> struct WideSched {
     using Plan = SplitPlan<8, H...>;
     using Shape = typename Plan::Shape;
+    static constexpr int L = 8, NL = Shape::n_layers;
+    static constexpr int N = Plan::max_stream_len() > 0 ? Plan::max_stream_len() : 1;
+    static constexpr int row_gene0(int layer, int j) { return Shape::layer_offset(layer) + j * (Shape::dims[layer] + 1); }
+    static constexpr int row_word0(int layer, int j) { return row_gene0(layer, j) / 4; }
+    static constexpr int row_words(int layer, int j) { return (row_gene0(layer, j + 1) - 1) / 4 - row_word0(layer, j) + 1; }
+    static constexpr int max_items()
+    {
+        int m = 1;
+        for (int k = 0; k < L; ++k)
+            for (int l = 0; l < NL; ++l) {
+                int n = 0;
+                for (int j = Plan::row_begin(l, k); j < Plan::row_end(l, k); ++j) n += row_words(l, j);
+                m = n > m ? n : m;
+            }
+        return m;
+    }
+    static constexpr int MI = max_items();
+    struct Tables {
+        int len[L], n_lds[L], n_reg[L], lds_base[L + 1];
+        int cls[L][N], idx[L][N];                          // class of stream position s, its index within the class
+        int pos_lds[L][N], pos_reg[L][N];                  // stream position of the j-th word of a class (the fill)
+        int n_items[L][NL];
+        int item_row[L][NL][MI], item_pos[L][NL][MI];      // the i-th item of a layer: row, stream position
+        int item_seq[L][NL][MI];                           // ... its number among the wavefront's LDS items, or -1
+        int n_seq[L], seq_row[L][NL * MI];                 // LDS row (index within the class) the q-th LDS item reads
+    };
+    static constexpr Tables build()
+    {
+        Tables t{};
+        t.lds_base[0] = 0;
+        for (int k = 0; k < L; ++k) {
+            const int len = Plan::stream_len(k);
+            const int last0 = Plan::stream_pos(NL - 1, k), last_len = len - last0;
+            const int regs = RegWords < len ? RegWords : len;
+            const int regs_last = regs < last_len ? regs : last_len;          // the output layer's words take registers first
+            const int regs_rest = regs - regs_last, rest = last0;
+            t.len[k] = len;
+            int n_lds = 0, n_reg = 0;
+            for (int s = 0; s < len; ++s) {
+                bool reg = false;
+                if (s >= last0) reg = s - last0 < regs_last;
+                else reg = regs_rest > 0 && (long long)(s + 1) * regs_rest / rest != (long long)s * regs_rest / rest;
+                t.cls[k][s] = reg ? 1 : 0;
+                if (reg) { t.idx[k][s] = n_reg; t.pos_reg[k][n_reg++] = s; }
+                else { t.idx[k][s] = n_lds; t.pos_lds[k][n_lds++] = s; }
+            }
+            t.n_lds[k] = n_lds; t.n_reg[k] = n_reg;
+            t.lds_base[k + 1] = t.lds_base[k] + n_lds;
+            int seq = 0;
+            for (int l = 0; l < NL; ++l) {
+                const int r0 = Plan::row_begin(l, k), r1 = Plan::row_end(l, k);
+                int n = 0, rounds = 0;
+                for (int j = r0; j < r1; ++j) rounds = row_words(l, j) > rounds ? row_words(l, j) : rounds;
+                for (int r = 0; r < rounds; ++r)
+                    for (int j = r0; j < r1; ++j) {
+                        if (r >= row_words(l, j)) continue;
+                        const int s = Plan::stream_pos(l, k) + (row_word0(l, j) + r - Plan::word_begin(l, k));
+                        t.item_row[k][l][n] = j;
+                        t.item_pos[k][l][n] = s;
+                        t.item_seq[k][l][n] = -1;
+                        if (t.cls[k][s] == 0) { t.item_seq[k][l][n] = seq; t.seq_row[k][seq++] = t.idx[k][s]; }
+                        ++n;
+                    }
+                t.n_items[k][l] = n;
+            }
+            t.n_seq[k] = seq;
+        }
+        return t;
+    }
+    static constexpr Tables T = build();
+    static constexpr int total_lds() { return T.lds_base[L]; }
+    static constexpr int total_reg()
+    {
+        int n = 0;
+        for (int k = 0; k < L; ++k) n += T.n_reg[k];
+        return n;
+    }
+};
+
+template <int RegWords, int... H> struct WidePlan {
+    using Sched = WideSched<RegWords, H...>;
+    using Plan = typename Sched::Plan;
+    using Shape = typename Plan::Shape;
     static constexpr int NL = Shape::n_layers;
-    // LDS share per wavefront is proportional to its stream (KeepPlanOf); ask for enough that the longest stream's rest fits
-    static constexpr int kKeepWords = KeepKiB * 1024 / (64 * 16);
-    using Keep = KeepPlanOf<Plan, kKeepWords, RegWords, true>;
-    static constexpr int kLdsRows = Keep::T.lds_base[8];
     // the j-th wavefront WITHOUT a row of the output layer does side job j (0, 1, 2: sin / cos of roll, pitch, yaw)
     static constexpr int side_job(int k)
     {
@@ -62,35 +155,39 @@ template <int KeepKiB, int RegWords, int... H> struct WidePlan {
         for (int q = 0; q < 8; ++q) j += Plan::row_end(NL - 1, q) == Plan::row_begin(NL - 1, q) ? 1 : 0;
         return j;
     }
-    // exchange rows: the layers' outputs (the last layer's four are the thrusts), then sin / cos of the three angles
+    // exchange rows: the layers' outputs (the last layer's four are the thrusts), then sin / cos of the three angles,
+    // 1 / cos(pitch), and whether the drone has reached its coin
     static constexpr int kThrustRow = Plan::xch_row(NL - 1);
     static constexpr int kScRow = Plan::xch_row(NL);
-    static constexpr int kXchRows = kScRow + 6;
-    static constexpr int kLdsBytes = (kLdsRows + LD_WIDE_KEEP_DEPTH) * 64 * 16 + kXchRows * 64 * 4 +
+    static constexpr int kInvCpRow = kScRow + 6;
+    static constexpr int kCoinRow = kScRow + 7;
+    static constexpr int kXchRows = kScRow + 8;
+    static constexpr int kKeptRows = Sched::total_lds() + LD_WIDE_KEEP_DEPTH;     // (+ the top-of-step reads of a wavefront with fewer LDS items than it keeps in flight)
+    static constexpr int kLdsBytes = kKeptRows * 64 * 16 + kXchRows * 64 * 4 +
                                      (LD_MAX_COINS * LD_COIN_STRIDE + LD_MAX_WALLS * LD_WALL_STRIDE) * 4;
-    // everything on chip, within the CU's LDS, and three wavefronts free for the angles
-    static constexpr bool fits = Shape::W <= 512 && Keep::max_loaded_len() == 0 && kLdsBytes <= 160 * 1024 && side_waves() >= 3;
+    // everything on chip within the CU's LDS, and four wavefronts free for the angles and the coin
+    static constexpr bool fits = Shape::W <= 512 && kLdsBytes <= 160 * 1024 && side_waves() >= 4;
 };
 
-template <int KeepKiB, int RegWords, int... H>
+template <int RegWords, int... H>
 __global__ void __launch_bounds__(512)
 fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __restrict__ coins, const double* __restrict__ walls,
                 const GeneWord<float>* __restrict__ genomes, float* __restrict__ fstate, int32_t* __restrict__ istate,
                 const int64_t n, const int64_t begin, const int64_t end, const int32_t n_steps)
 {
     using Real = float;
-    using WP = WidePlan<KeepKiB, RegWords, H...>;
+    using WP = WidePlan<RegWords, H...>;
     using Plan = typename WP::Plan;
     using Shape = typename WP::Shape;
-    using Keep = typename WP::Keep;
-    constexpr int L = 8, NL = Shape::n_layers, MW = Shape::max_width();
-    constexpr int KD = LD_WIDE_KEEP_DEPTH, FD = 4;              // kept words in flight from LDS; words in flight while filling
+    using Sched = typename WP::Sched;
+    constexpr int L = 8, NL = Shape::n_layers;
+    constexpr int KD = LD_WIDE_KEEP_DEPTH, FD = 4;              // LDS items in flight per lane; words in flight while filling
+    constexpr int AW = 16;                                      // window of a layer's inputs held in registers
     static_assert(WP::fits, "fly_wide_kernel: the layer spec's genes do not fit on chip");
-    static_assert(KD <= LD_SPLIT_KEEP_DEPTH, "KeepPlanOf pads its LDS rows by LD_SPLIT_KEEP_DEPTH");
 
     __shared__ Tables<Real> tab;
     __shared__ Real xch[WP::kXchRows][64];
-    __shared__ GeneWord<Real> kept[Keep::rows][64];
+    __shared__ GeneWord<Real> kept[WP::kKeptRows][64];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -115,24 +212,24 @@ fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __rest
     GeneWord<Real> rkept[RegWords > 0 ? RegWords : 1];
     wave_switch<L>(wave, [&](auto kc) __attribute__((always_inline)) {
         constexpr int K = decltype(kc)::value;
-        constexpr int R = Keep::count(K);
-        my_kept = &kept[Keep::base(K)][lane];
+        constexpr int R = Sched::T.n_lds[K];
+        my_kept = &kept[Sched::T.lds_base[K]][lane];
         GeneWord<Real> fill[FD];
         static_for<0, (R + FD - 1) / FD>([&](auto cc) __attribute__((always_inline)) {
             constexpr int c0 = decltype(cc)::value * FD, c1 = c0 + FD < R ? c0 + FD : R;
             static_for<c0, c1>([&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
-                constexpr int word = Plan::word_at(K, Keep::pos_of_kept(K, j));
+                constexpr int word = Plan::word_at(K, Sched::T.pos_lds[K][j]);
                 fill[j - c0] = load_word<Real>(genomes, lane_offset, word);
             });
             static_for<c0, c1>([&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
-                kept[Keep::base(K) + j][lane] = fill[j - c0];
+                kept[Sched::T.lds_base[K] + j][lane] = fill[j - c0];
             });
         });
-        static_for<0, Keep::reg_count(K)>([&](auto ic) __attribute__((always_inline)) {
+        static_for<0, Sched::T.n_reg[K]>([&](auto ic) __attribute__((always_inline)) {
             constexpr int r = decltype(ic)::value;
-            constexpr int word = Plan::word_at(K, Keep::pos_of_reg(K, r));
+            constexpr int word = Plan::word_at(K, Sched::T.pos_reg[K][r]);
             rkept[r] = load_word<Real>(genomes, lane_offset, word);
         });
     });
@@ -147,21 +244,34 @@ fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __rest
     const bool dead0 = (status_loaded & 1) || !valid;         // crashed earlier: frozen
     bool dead = dead0;
     int32_t flight_time = status_loaded >> 1;
-    auto angles_job = [&](int a) __attribute__((always_inline)) {
-        Real sn, cs;
-        Math<Real>::sincos(d.s[6 + a], &sn, &cs);
-        xch[WP::kScRow + 2 * a][lane] = sn;
-        xch[WP::kScRow + 2 * a + 1][lane] = cs;
+    // The side jobs: what the next rigid-body step needs that does not depend on the controller's output.  Jobs 0-2: sin / cos
+    // of one Euler angle each (the pitch's also 1 / cos); job 3: has the drone reached the coin it is flying to (objects/coins.py:17-25
+    // on the post-step position: the test the NEXT iteration of fly()'s loop starts with, flight/__init__.py:44-52).
+    Real c[LD_COIN_STRIDE];
+    auto side_job = [&](auto jobc) __attribute__((always_inline)) {
+        constexpr int job = decltype(jobc)::value;
+        if constexpr (job >= 0 && job < 3) {
+            Real sn, cs;
+            Math<Real>::sincos(d.s[6 + job], &sn, &cs);
+            xch[WP::kScRow + 2 * job][lane] = sn;
+            xch[WP::kScRow + 2 * job + 1][lane] = cs;
+            if constexpr (job == 1) xch[WP::kInvCpRow][lane] = (Real)1 / cs;
+        } else if constexpr (job == 3) {
+            Real cc[LD_COIN_STRIDE];
+            const bool there = current_coin<Real>(ep, tab.coins, ncoll, cc);
+            xch[WP::kCoinRow][lane] = there && coin_distance<Real>(cc, d.s) < cc[3] ? (Real)1 : (Real)0;
+        }
     };
+    split_barrier();                                          // the tables are in LDS
     wave_switch<L>(wave, [&](auto kc) __attribute__((always_inline)) {
         constexpr int K = decltype(kc)::value;
-        constexpr int job = WP::side_job(K);
-        if constexpr (job >= 0 && job < 3) angles_job(job);
-        if constexpr (job == 3 || (job < 0 && WP::side_waves() < 4 && K == 7)) {
+        side_job(std::integral_constant<int, WP::side_job(K)>{});
+        if constexpr (K == 7) {
 #pragma unroll
             for (int k = 0; k < LD_N_OUTPUTS; ++k) xch[WP::kThrustRow + k][lane] = d.u[k];
         }
     });
+    current_coin<Real>(ep, tab.coins, ncoll, c);
     split_barrier();
 
     GeneWord<Real> kring[KD];
@@ -171,26 +281,30 @@ fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __rest
     for (int32_t t = 0; t < n_steps; ++t) {
         if (t > 0 && __all(dead)) break;                      // every wavefront of the workgroup sees the same 64 drones
         LD_STAMP(st_top)
-#pragma unroll
-        for (int j = 0; j < KD; ++j) kring[j] = my_kept[j * 64];          // (a wavefront with fewer kept words reads rows it never uses)
+        // the wavefront's first LDS items: in flight while the rigid-body step runs
+        wave_switch<L>(wave, [&](auto kc) __attribute__((always_inline)) {
+            constexpr int K = decltype(kc)::value;
+            static_for<0, (KD < Sched::T.n_seq[K] ? KD : Sched::T.n_seq[K])>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int q = decltype(qc)::value;
+                kring[q] = my_kept[Sched::T.seq_row[K][q] * 64];
+            });
+        });
         // ---- the controller's output of the last step acts now (flight/__init__.py:89; none after a crash), and the
         // angles' sin / cos come from the wavefronts that computed them beside the output layer.  A drone that crashed
         // earlier keeps the state it crashed with (:80-87): its lane sits out the step (the other kernels commit by selects,
         // to keep their gene loads in flight across the step; here nothing is in flight, and a masked lane costs no copy
         // of the state)
-        Real c[LD_COIN_STRIDE];
         if (!dead) {
             Real sc[6];
 #pragma unroll
             for (int k = 0; k < LD_N_OUTPUTS; ++k) d.u[k] = xch[WP::kThrustRow + k][lane];
 #pragma unroll
             for (int k = 0; k < 6; ++k) sc[k] = xch[WP::kScRow + k][lane];
-            // ---- flight/__init__.py:41-52, :79
+            const Real inv_cp = xch[WP::kInvCpRow][lane];
+            // ---- flight/__init__.py:41-52, :79 (c is the coin the drone was flying to, and was shown, when the test was made)
             int32_t r = reward + ep.reward_time;
-            if (current_coin<Real>(ep, tab.coins, ncoll, c)) {
-                if (coin_distance<Real>(c, d.s) < c[3]) { r += (int32_t)c[4]; ncoll += 1; }
-            }
-            dead = measure<Real, false>(sim, ep, tab.walls, d, r, sc);
+            if (xch[WP::kCoinRow][lane] != (Real)0) { r += (int32_t)c[4]; ncoll += 1; }
+            dead = measure<Real, false>(sim, ep, tab.walls, d, r, sc, &inv_cp);
             reward = r;
             flight_time += 1;
         }
@@ -202,52 +316,67 @@ fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __rest
 #endif
 
         // ---- controller on the post-step state (evolve/brain.py:41-54); frozen lanes compute on their frozen state and
-        // the result is discarded above
-        Real act[MW];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) act[k] = d.s[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) act[12 + k] = c[k];
+        // the result is never taken up
         wave_switch<L>(wave, [&](auto kc) __attribute__((always_inline)) {
             constexpr int K = decltype(kc)::value;
             static_for<0, NL>([&](auto lc) __attribute__((always_inline)) {
                 constexpr int layer = decltype(lc)::value;
-                constexpr int n_in = Shape::dims[layer], n_out = Shape::dims[layer + 1];
+                constexpr int n_in = Shape::dims[layer];
                 constexpr bool last = layer == NL - 1;
                 constexpr int r0 = Plan::row_begin(layer, K), r1 = Plan::row_end(layer, K);
-                constexpr int g0 = Plan::gene_begin(layer, K), g1 = Plan::gene_end(layer, K);
-                constexpr int wa = Plan::word_begin(layer, K), wb = Plan::word_end(layer, K);
-                constexpr int base = Plan::stream_pos(layer, K);
-                Real out[r1 > r0 ? r1 - r0 : 1];
-                Real acc = (Real)0;
-                static_for<wa, wb>([&](auto wc) __attribute__((always_inline)) {
-                    constexpr int w = decltype(wc)::value;
-                    constexpr int s = base + (w - wa);
-                    constexpr bool from_lds = Keep::cls(K, s) == 0;
-                    constexpr int kj = from_lds ? Keep::idx(K, s) : 0, ri = from_lds ? 0 : Keep::idx(K, s);
-                    const GeneWord<Real> v = from_lds ? kring[kj % KD] : rkept[ri];
-                    static_for<0, 4>([&](auto cc) __attribute__((always_inline)) {
-                        constexpr int cidx = decltype(cc)::value;
-                        constexpr int p = 4 * w + cidx;
-                        if constexpr (p >= g0 && p < g1) {
-                            constexpr int q = p - Shape::layer_offset(layer);
-                            constexpr int j = q / (n_in + 1), k = q % (n_in + 1);
-                            if constexpr (k == 0) {
-                                acc = mac<Real, true>(v.g[cidx], act[0], (Real)0);
-                            } else if constexpr (k < n_in) {
-                                acc = mac<Real, true>(v.g[cidx], act[k], acc);
-                            } else {
-                                acc = acc + v.g[cidx];
-                                out[j - r0] = last ? sigmoid04<Real>(acc) : relu<Real>(acc);
-                            }
+                constexpr int base = Plan::stream_pos(layer, K), wa = Plan::word_begin(layer, K);
+                constexpr int in_row = layer > 0 ? Plan::xch_row(layer - 1) : 0;
+                constexpr int n_items = Sched::T.n_items[K][layer];
+                constexpr int rows = r1 > r0 ? r1 - r0 : 1;
+                Real acc[rows];
+                Real aw[AW];                                   // inputs k, k + 16, ... share a register; a row is at most 7 inputs from any other
+                // input k of this layer: the post-step state and the coin (first layer), or the previous layer's output row in LDS
+                auto fetch = [&](auto kc2) __attribute__((always_inline)) {
+                    constexpr int k = decltype(kc2)::value;
+                    if constexpr (layer == 0) aw[k % AW] = k < 12 ? d.s[k] : c[k - 12];
+                    else aw[k % AW] = xch[in_row + k][lane];
+                };
+                if constexpr (r1 > r0) {
+                    static_for<0, (8 < n_in ? 8 : n_in)>(fetch);
+                    static_for<0, n_items>([&](auto ic) __attribute__((always_inline)) {
+                        constexpr int it = decltype(ic)::value;
+                        constexpr int j = Sched::T.item_row[K][layer][it], s = Sched::T.item_pos[K][layer][it];
+                        constexpr int seq = Sched::T.item_seq[K][layer][it];
+                        constexpr int w = wa + (s - base);
+                        constexpr int g0 = Sched::row_gene0(layer, j), g1 = g0 + n_in + 1;
+                        // the round that starts here reads inputs up to 4 (round + 1) + 3: request the four after those
+                        if constexpr (j == r0) {
+                            constexpr int round = w - Sched::row_word0(layer, j);
+                            static_for<(4 * round + 8 < n_in ? 4 * round + 8 : n_in), (4 * round + 12 < n_in ? 4 * round + 12 : n_in)>(fetch);
                         }
+                        const GeneWord<Real> v = seq >= 0 ? kring[(seq >= 0 ? seq : 0) % KD] : rkept[Sched::T.idx[K][s]];
+                        static_for<0, 4>([&](auto cc) __attribute__((always_inline)) {
+                            constexpr int cidx = decltype(cc)::value;
+                            constexpr int p = 4 * w + cidx;
+                            if constexpr (p >= g0 && p < g1) {
+                                constexpr int k = p - g0;
+                                if constexpr (k == 0) {
+                                    acc[j - r0] = mac<Real, true>(v.g[cidx], aw[0], (Real)0);
+                                } else if constexpr (k < n_in) {
+                                    acc[j - r0] = mac<Real, true>(v.g[cidx], aw[k % AW], acc[j - r0]);
+                                } else {
+                                    const Real sum = acc[j - r0] + v.g[cidx];
+                                    xch[Plan::xch_row(layer) + j][lane] = last ? sigmoid04<Real>(sum) : relu<Real>(sum);
+                                }
+                            }
+                        });
+                        if constexpr (seq >= 0) {
+                            if constexpr (seq + KD < Sched::T.n_seq[K]) kring[seq % KD] = my_kept[Sched::T.seq_row[K][seq + KD] * 64];
+                        }
+                        // Behind the last row's word of a round nothing crosses: the scheduler would sink every LDS read to just
+                        // above its first use and give all of them one set of registers, and the wavefront would sit out each
+                        // read's latency; inside a round (one word of every row: independent chains) it is free
+                        if constexpr (it + 1 == n_items || Sched::T.item_row[K][layer][it + 1 < n_items ? it + 1 : it] <= j)
+                            __builtin_amdgcn_sched_barrier(LD_WIDE_SCHED_MASK);
                     });
-                    if constexpr (from_lds && kj + KD < Keep::count(K)) kring[kj % KD] = my_kept[(kj + KD) * 64];
-                });
-#pragma unroll
-                for (int j = r0; j < r1; ++j) xch[Plan::xch_row(layer) + j][lane] = out[j - r0];
-                // beside the output layer: sin / cos of the angles the next step starts from
-                if constexpr (last && WP::side_job(K) >= 0 && WP::side_job(K) < 3) angles_job(WP::side_job(K));
+                }
+                // beside the output layer: what the next step starts from
+                if constexpr (last) side_job(std::integral_constant<int, WP::side_job(K)>{});
                 LD_STAMP(st_work)
                 LD_STAMP_ADD(1 + 2 * layer, st_prev, st_work)
                 split_barrier();
@@ -256,10 +385,6 @@ fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __rest
 #ifdef LD_DIAG_STAMPS
                 st_prev = st_bar;
 #endif
-                if constexpr (!last) {
-#pragma unroll
-                    for (int j = 0; j < n_out; ++j) act[j] = xch[Plan::xch_row(layer) + j][lane];
-                }
             });
         });
     }
@@ -284,20 +409,21 @@ fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __rest
 }
 
 // Accounting (ld_fly_steps_kept_words_f32): gene words per drone kept in LDS, held in registers, loaded every timestep (none).
-template <int KeepKiB, int RegWords, int... H>
+template <int RegWords, int... H>
 inline void wide_kept_words(int64_t* lds, int64_t* regs, int64_t* streamed)
 {
-    using Keep = typename WidePlan<KeepKiB, RegWords, H...>::Keep;
-    *lds = *regs = *streamed = 0;
-    for (int k = 0; k < 8; ++k) { *lds += Keep::T.n[0][k]; *regs += Keep::T.n[1][k]; *streamed += Keep::T.n[2][k]; }
+    using Sched = typename WidePlan<RegWords, H...>::Sched;
+    *lds = Sched::total_lds();
+    *regs = Sched::total_reg();
+    *streamed = 0;
 }
 
-template <int KeepKiB, int RegWords, int... H>
+template <int RegWords, int... H>
 int launch_fly_wide(const ld_sim_params* sim, const ld_episode_params* ep, const double* coins, const double* walls,
                     const float* genomes, float* fstate, int32_t* istate, int64_t n, int64_t begin, int64_t end,
                     int32_t n_steps, hipStream_t stream)
 {
-    hipLaunchKernelGGL((fly_wide_kernel<KeepKiB, RegWords, H...>), dim3(blocks_for(end - begin, 64)), dim3(512), 0, stream,
+    hipLaunchKernelGGL((fly_wide_kernel<RegWords, H...>), dim3(blocks_for(end - begin, 64)), dim3(512), 0, stream,
                        make_sim<float>(*sim), make_ep<float>(*ep), coins, walls, reinterpret_cast<const GeneWord<float>*>(genomes),
                        fstate, istate, n, begin, end, n_steps);
     return check_launch("fly_wide_kernel");

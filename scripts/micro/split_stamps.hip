@@ -43,7 +43,7 @@ int run(int64_t n, int steps, int reps)
         if (ld_population_reset_f32(fstate, istate, n, nullptr, nullptr)) return 1;
         CHECK(hipEventRecord(e0, nullptr));
         if constexpr (S == 8) {
-            if (ld::launch_fly_wide<LD_WIDE_KEEP_KIB, LD_WIDE_REG_WORDS, 32, 32>(&sim, &ep, coins, nullptr, genomes, fstate, istate, n, 0, n, steps, nullptr)) return 1;
+            if (ld::launch_fly_wide<LD_WIDE_REG_WORDS, 32, 32>(&sim, &ep, coins, nullptr, genomes, fstate, istate, n, 0, n, steps, nullptr)) return 1;
         } else
         if (ld::launch_fly_split<float, false, 8, S == 8 ? 1 : S, Keep, (Keep == 0 ? 0 : S == 1 ? LD_SPLIT_REG_WORDS_64 : S == 2 ? LD_SPLIT_REG_WORDS_32 : S == 3 ? LD_SPLIT_REG_WORDS_48 : 0), 32, 32>(&sim, &ep, coins, nullptr, genomes, fstate, istate, n, 0, n, steps, nullptr)) return 1;
         CHECK(hipEventRecord(e1, nullptr));

@@ -247,7 +247,7 @@ def _replicated(hidden, m, n, seed):
 def test_full_size_config4_shard(Population, torch):
     """One GPU's share of BASELINE config 4: 32 768 drones x 4 000 steps, 15-32-32-4, 3-coin chain (the
     launch geometry this shard gets: 512 timesteps per launch, all 32 768 drones in one launch, one workgroup of 8 wavefronts per
-    genome block (fly_wide_kernel), all of its 64 drones' genes held in registers (320 words per drone) and LDS (108) for the launch).  Size-independent
+    genome block (fly_wide_kernel), all of its 64 drones' genes held in registers (304 words per drone) and LDS (124) for the launch).  Size-independent
     properties: genomes replicated from a 256-drone population under a random permutation give the
     permuted small-population results bit for bit; a re-run is bit-identical; one launch per timestep
     and the resident engine give the same records."""
@@ -261,7 +261,7 @@ def test_full_size_config4_shard(Population, torch):
     pop = Population(n, hidden, coins=coins)
     pop.set_genomes(torch.as_tensor(genes_m, dtype=torch.float32, device="cuda")[torch.as_tensor(src, device="cuda")])
     geo = pop.rollout_geometry(T)
-    assert geo == {"steps_per_launch": 512, "waves_per_block": 8, "launches": 8, "tile_drones": 32768, "lds_words": 108, "register_words": 320, "streamed_words": 0}
+    assert geo == {"steps_per_launch": 512, "waves_per_block": 8, "launches": 8, "tile_drones": 32768, "lds_words": 124, "register_words": 304, "streamed_words": 0}
     pop.fly(T)
     got = pop.results()
     for f in ("reward", "flight_time", "coins", "crashed", "distance_to_coin"):
@@ -594,7 +594,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     top = max(r["levels"].values(), key=lambda v: v["frac"])
     assert r["frac"] == top["frac"] and r["achieved"] == top["achieved"] and r["peak"] == top["peak"] and 0 < r["frac"] <= 1.0
     assert r["levels"]["hbm"]["peak"] == 8000.0 and r["unit"] in ("GB/s", "G wave-instructions/s")
-    assert r["launch_us"] > 0 and "traffic" in r and r["lds_words_per_drone"] == 12 and r["register_words_per_drone"] == 424 and r["streamed_words_per_drone"] == 0   # workgroups of 32 drones, halves paired
+    assert r["launch_us"] > 0 and "traffic" in r and r["lds_words_per_drone"] == 124 and r["register_words_per_drone"] == 304 and r["streamed_words_per_drone"] == 0   # workgroups of 64 drones, fly_wide_kernel
     assert "roofline_hbm_bound" in d and d["one_timestep_per_launch"]["bound"] == "hbm"
     assert "exchange_bytes_per_generation_per_rank" in d["generation"]
     c = d["cpu_baseline"]

@@ -182,21 +182,21 @@ def test_argument_validation_without_gpu(lib):
     geo = lambda h, n, T: (lib.ld_fly_rollout_geometry_f32(C.byref(MlpSpec.from_hidden(h)), n, T, C.byref(k), C.byref(w), C.byref(m),
                                                             C.byref(tile)), k.value, w.value, m.value, tile.value)
     # nets of up to 512 gene words keep their genes on chip for the launch: no tiles, 512 timesteps per launch (the genes are
-    # loaded once per launch), workgroups of 8 wavefronts -- of 64 drones (fly_wide_kernel: every gene on chip) where the launch
-    # gives every CU one or the net is small (<= 300 words), of 32 drones (fly_pair_kernel) otherwise
-    assert geo((32, 32), 65536, 2000) == (OK, 512, 8, 4, 65536) and geo((32, 32), 8192, 2000) == (OK, 512, 16, 4, 8192)
+    # loaded once per launch), workgroups of 8 wavefronts x 64 drones (fly_wide_kernel) where every gene word of 64 drones fits
+    # on chip -- all the shipped specs of up to 512 words do
+    assert geo((32, 32), 65536, 2000) == (OK, 512, 8, 4, 65536) and geo((32, 32), 8192, 2000) == (OK, 512, 8, 4, 8192)
     assert geo((32, 32), 32768, 4000) == (OK, 512, 8, 8, 32768)           # config 4 shard
-    assert geo((32, 32), 16384, 2000) == (OK, 512, 8, 4, 16384) and geo((32, 32), 1024, 2000) == (OK, 512, 16, 4, 1024)
+    assert geo((32, 32), 16384, 2000) == (OK, 512, 8, 4, 16384) and geo((32, 32), 1024, 2000) == (OK, 512, 8, 4, 1024)
     assert geo((16, 16), 65536, 2000) == (OK, 512, 8, 4, 65536) and geo((16, 16), 1024, 2000) == (OK, 512, 8, 4, 1024)   # config 2
-    assert geo((64,), 8192, 100) == (OK, 512, 16, 1, 8192) and geo((64,), 65536, 100) == (OK, 512, 8, 1, 65536) and geo((24, 24), 8192, 100)[2] == 8
+    assert geo((64,), 8192, 100) == (OK, 512, 8, 1, 8192) and geo((64,), 65536, 100) == (OK, 512, 8, 1, 65536) and geo((24, 24), 8192, 100)[2] == 8
     in_lds, in_regs, streamed = C.c_int64(), C.c_int64(), C.c_int64()
     words = lambda h, w, steps: (lib.ld_fly_steps_kept_words_f32(C.byref(MlpSpec.from_hidden(h)), w, steps, C.byref(in_lds), C.byref(in_regs),
                                                                  C.byref(streamed)), in_lds.value, in_regs.value, streamed.value)
     # (gene words per drone kept in LDS, held in registers, loaded every timestep): 32-32 has 428 (three words straddle two
     # wavefronts' rows and are loaded by both)
     assert words((32, 32), 11, 64)[1:] == (176, 96, 156)
-    # workgroups of 64 drones (fly_wide_kernel): 40 words per wavefront in registers, the rest in LDS, nothing loaded per timestep
-    assert words((32, 32), 8, 64)[1:] == (108, 320, 0) and words((64,), 8, 64)[1:] == (36, 288, 0) and words((24, 24), 8, 64)[1:] == (0, 280, 0)
+    # workgroups of 64 drones (fly_wide_kernel): 38 words per wavefront in registers, the rest in LDS, nothing loaded per timestep
+    assert words((32, 32), 8, 64)[1:] == (124, 304, 0) and words((64,), 8, 64)[1:] == (44, 280, 0) and words((24, 24), 8, 64)[1:] == (2, 278, 0)
     assert words((16, 16), 8, 64)[1:] == (0, 156, 0) and words((10, 10), 8, 64)[1:] == (0, 88, 0)
     # ... and the run-time restatement of that plan, which the policy asks for specs specialised at run time, agrees with the kernels' own
     wide_lds, wide_regs = C.c_int64(), C.c_int64()

@@ -246,14 +246,15 @@ bool wide_plan(const ld_mlp_spec& spec, int64_t* in_lds, int64_t* in_registers)
             offset += (int64_t)dims[l + 1] * stride;
         }
     }
-    for (int l = 0; l < layers; ++l) rows += dims[l + 1];
+    for (int l = 0; l < layers; ++l) rows += (dims[l + 1] + 3) / 4;      // 16-byte words of a drone's row of the exchange image
+    rows = (rows + 2) | 1;
     int64_t lds = 0, regs = 0;
     for (int k = 0; k < L; ++k) {
         const int64_t held = LD_WIDE_REG_WORDS < len[k] ? LD_WIDE_REG_WORDS : len[k];
         regs += held;
         lds += len[k] - held;
     }
-    const int64_t lds_bytes = (lds + LD_WIDE_KEEP_DEPTH) * 64 * 16 + (rows + 8) * 64 * 4 +
+    const int64_t lds_bytes = (lds + LD_WIDE_KEEP_DEPTH) * 64 * 16 + rows * 64 * 16 +
                               (LD_MAX_COINS * LD_COIN_STRIDE + LD_MAX_WALLS * LD_WALL_STRIDE) * 4;
     if (lds_bytes > 160 * 1024) return false;
     if (in_lds) *in_lds = lds;

@@ -155,15 +155,22 @@ template <int RegWords, int... H> struct WidePlan {
         for (int q = 0; q < 8; ++q) j += Plan::row_end(NL - 1, q) == Plan::row_begin(NL - 1, q) ? 1 : 0;
         return j;
     }
-    // exchange rows: the layers' outputs (the last layer's four are the thrusts), then sin / cos of the three angles,
-    // 1 / cos(pitch), and whether the drone has reached its coin
-    static constexpr int kThrustRow = Plan::xch_row(NL - 1);
-    static constexpr int kScRow = Plan::xch_row(NL);
-    static constexpr int kInvCpRow = kScRow + 6;
-    static constexpr int kCoinRow = kScRow + 7;
-    static constexpr int kXchRows = kScRow + 8;
+    // The exchange image in LDS: per drone one row of 16-byte words -- every layer's outputs (the last layer's four are the
+    // thrusts), then {sin, cos} of roll and pitch, then {sin, cos} of yaw, 1 / cos(pitch) and whether the drone has reached
+    // its coin.  [drone][word] with an ODD number of words per row: a lane reads four consecutive inputs with one
+    // conflict-free ds_read_b128 (256 B per clock and CU; the [neuron][drone] rows of the other kernels are read value by
+    // value, ds_read_b32: 128 B per clock), and a wavefront stores four consecutive outputs with one ds_write_b128.
+    static constexpr int out_word(int layer)
+    {
+        int w = 0;
+        for (int l = 0; l < layer; ++l) w += (Shape::dims[l + 1] + 3) / 4;
+        return w;
+    }
+    static constexpr int kThrustWord = out_word(NL - 1);
+    static constexpr int kScWord = out_word(NL);
+    static constexpr int kXchWords = (kScWord + 2) | 1;
     static constexpr int kKeptRows = Sched::total_lds() + LD_WIDE_KEEP_DEPTH;     // (+ the top-of-step reads of a wavefront with fewer LDS items than it keeps in flight)
-    static constexpr int kLdsBytes = kKeptRows * 64 * 16 + kXchRows * 64 * 4 +
+    static constexpr int kLdsBytes = kKeptRows * 64 * 16 + kXchWords * 64 * 16 +
                                      (LD_MAX_COINS * LD_COIN_STRIDE + LD_MAX_WALLS * LD_WALL_STRIDE) * 4;
     // everything on chip within the CU's LDS, and four wavefronts free for the angles and the coin
     static constexpr bool fits = Shape::W <= 512 && kLdsBytes <= 160 * 1024 && side_waves() >= 4;
@@ -186,7 +193,7 @@ fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __rest
     static_assert(WP::fits, "fly_wide_kernel: the layer spec's genes do not fit on chip");
 
     __shared__ Tables<Real> tab;
-    __shared__ Real xch[WP::kXchRows][64];
+    __shared__ GeneWord<Real> xch[64][WP::kXchWords];
     __shared__ GeneWord<Real> kept[WP::kKeptRows][64];
 
     const int lane = threadIdx.x & 63;
@@ -248,18 +255,19 @@ fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __rest
     // of one Euler angle each (the pitch's also 1 / cos); job 3: has the drone reached the coin it is flying to (objects/coins.py:17-25
     // on the post-step position: the test the NEXT iteration of fly()'s loop starts with, flight/__init__.py:44-52).
     Real c[LD_COIN_STRIDE];
+    Real* const xf = reinterpret_cast<Real*>(&xch[lane][0]);      // this drone's row, value by value
     auto side_job = [&](auto jobc) __attribute__((always_inline)) {
         constexpr int job = decltype(jobc)::value;
         if constexpr (job >= 0 && job < 3) {
             Real sn, cs;
             Math<Real>::sincos(d.s[6 + job], &sn, &cs);
-            xch[WP::kScRow + 2 * job][lane] = sn;
-            xch[WP::kScRow + 2 * job + 1][lane] = cs;
-            if constexpr (job == 1) xch[WP::kInvCpRow][lane] = (Real)1 / cs;
+            xf[4 * WP::kScWord + 2 * job] = sn;
+            xf[4 * WP::kScWord + 2 * job + 1] = cs;
+            if constexpr (job == 1) xf[4 * WP::kScWord + 6] = (Real)1 / cs;
         } else if constexpr (job == 3) {
             Real cc[LD_COIN_STRIDE];
             const bool there = current_coin<Real>(ep, tab.coins, ncoll, cc);
-            xch[WP::kCoinRow][lane] = there && coin_distance<Real>(cc, d.s) < cc[3] ? (Real)1 : (Real)0;
+            xf[4 * WP::kScWord + 7] = there && coin_distance<Real>(cc, d.s) < cc[3] ? (Real)1 : (Real)0;
         }
     };
     split_barrier();                                          // the tables are in LDS
@@ -268,7 +276,7 @@ fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __rest
         side_job(std::integral_constant<int, WP::side_job(K)>{});
         if constexpr (K == 7) {
 #pragma unroll
-            for (int k = 0; k < LD_N_OUTPUTS; ++k) xch[WP::kThrustRow + k][lane] = d.u[k];
+            for (int k = 0; k < LD_N_OUTPUTS; ++k) xf[4 * WP::kThrustWord + k] = d.u[k];
         }
     });
     current_coin<Real>(ep, tab.coins, ncoll, c);
@@ -295,15 +303,14 @@ fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __rest
         // to keep their gene loads in flight across the step; here nothing is in flight, and a masked lane costs no copy
         // of the state)
         if (!dead) {
-            Real sc[6];
+            const GeneWord<Real> tw = xch[lane][WP::kThrustWord], s0 = xch[lane][WP::kScWord], s1 = xch[lane][WP::kScWord + 1];
 #pragma unroll
-            for (int k = 0; k < LD_N_OUTPUTS; ++k) d.u[k] = xch[WP::kThrustRow + k][lane];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) sc[k] = xch[WP::kScRow + k][lane];
-            const Real inv_cp = xch[WP::kInvCpRow][lane];
+            for (int k = 0; k < LD_N_OUTPUTS; ++k) d.u[k] = tw.g[k];
+            const Real sc[6] = {s0.g[0], s0.g[1], s0.g[2], s0.g[3], s1.g[0], s1.g[1]};
+            const Real inv_cp = s1.g[2];
             // ---- flight/__init__.py:41-52, :79 (c is the coin the drone was flying to, and was shown, when the test was made)
             int32_t r = reward + ep.reward_time;
-            if (xch[WP::kCoinRow][lane] != (Real)0) { r += (int32_t)c[4]; ncoll += 1; }
+            if (s1.g[3] != (Real)0) { r += (int32_t)c[4]; ncoll += 1; }
             dead = measure<Real, false>(sim, ep, tab.walls, d, r, sc, &inv_cp);
             reward = r;
             flight_time += 1;
@@ -325,29 +332,34 @@ fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __rest
                 constexpr bool last = layer == NL - 1;
                 constexpr int r0 = Plan::row_begin(layer, K), r1 = Plan::row_end(layer, K);
                 constexpr int base = Plan::stream_pos(layer, K), wa = Plan::word_begin(layer, K);
-                constexpr int in_row = layer > 0 ? Plan::xch_row(layer - 1) : 0;
+                constexpr int in_word = layer > 0 ? WP::out_word(layer - 1) : 0;
                 constexpr int n_items = Sched::T.n_items[K][layer];
                 constexpr int rows = r1 > r0 ? r1 - r0 : 1;
-                Real acc[rows];
-                Real aw[AW];                                   // inputs k, k + 16, ... share a register; a row is at most 7 inputs from any other
-                // input k of this layer: the post-step state and the coin (first layer), or the previous layer's output row in LDS
-                auto fetch = [&](auto kc2) __attribute__((always_inline)) {
-                    constexpr int k = decltype(kc2)::value;
-                    if constexpr (layer == 0) aw[k % AW] = k < 12 ? d.s[k] : c[k - 12];
-                    else aw[k % AW] = xch[in_row + k][lane];
+                Real acc[rows], out[rows];
+                GeneWord<Real> aw[AW / 4];                     // inputs 4 m ... 4 m + 3 in word m mod 4; a row is at most 7 inputs from any other
+                // word m of this layer's inputs: the post-step state and the coin (first layer), or the previous layer's outputs in LDS
+                auto fetch = [&](auto mc) __attribute__((always_inline)) {
+                    constexpr int m = decltype(mc)::value;
+                    if constexpr (layer == 0) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) aw[m % (AW / 4)].g[q] = 4 * m + q < 12 ? d.s[4 * m + q < 12 ? 4 * m + q : 0] : c[4 * m + q < 15 ? 4 * m + q - 12 : 0];
+                    } else {
+                        aw[m % (AW / 4)] = xch[lane][in_word + m];
+                    }
                 };
+                constexpr int in_words = (n_in + 3) / 4;
                 if constexpr (r1 > r0) {
-                    static_for<0, (8 < n_in ? 8 : n_in)>(fetch);
+                    static_for<0, (2 < in_words ? 2 : in_words)>(fetch);
                     static_for<0, n_items>([&](auto ic) __attribute__((always_inline)) {
                         constexpr int it = decltype(ic)::value;
                         constexpr int j = Sched::T.item_row[K][layer][it], s = Sched::T.item_pos[K][layer][it];
                         constexpr int seq = Sched::T.item_seq[K][layer][it];
                         constexpr int w = wa + (s - base);
                         constexpr int g0 = Sched::row_gene0(layer, j), g1 = g0 + n_in + 1;
-                        // the round that starts here reads inputs up to 4 (round + 1) + 3: request the four after those
+                        // the round that starts here reads inputs up to 4 round + 3: request the word two rounds on
                         if constexpr (j == r0) {
                             constexpr int round = w - Sched::row_word0(layer, j);
-                            static_for<(4 * round + 8 < n_in ? 4 * round + 8 : n_in), (4 * round + 12 < n_in ? 4 * round + 12 : n_in)>(fetch);
+                            if constexpr (round + 2 < in_words) fetch(std::integral_constant<int, round + 2>{});
                         }
                         const GeneWord<Real> v = seq >= 0 ? kring[(seq >= 0 ? seq : 0) % KD] : rkept[Sched::T.idx[K][s]];
                         static_for<0, 4>([&](auto cc) __attribute__((always_inline)) {
@@ -356,12 +368,12 @@ fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __rest
                             if constexpr (p >= g0 && p < g1) {
                                 constexpr int k = p - g0;
                                 if constexpr (k == 0) {
-                                    acc[j - r0] = mac<Real, true>(v.g[cidx], aw[0], (Real)0);
+                                    acc[j - r0] = mac<Real, true>(v.g[cidx], aw[0].g[0], (Real)0);
                                 } else if constexpr (k < n_in) {
-                                    acc[j - r0] = mac<Real, true>(v.g[cidx], aw[k % AW], acc[j - r0]);
+                                    acc[j - r0] = mac<Real, true>(v.g[cidx], aw[(k / 4) % (AW / 4)].g[k % 4], acc[j - r0]);
                                 } else {
                                     const Real sum = acc[j - r0] + v.g[cidx];
-                                    xch[Plan::xch_row(layer) + j][lane] = last ? sigmoid04<Real>(sum) : relu<Real>(sum);
+                                    out[j - r0] = last ? sigmoid04<Real>(sum) : relu<Real>(sum);
                                 }
                             }
                         });
@@ -373,6 +385,18 @@ fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __rest
                         // read's latency; inside a round (one word of every row: independent chains) it is free
                         if constexpr (it + 1 == n_items || Sched::T.item_row[K][layer][it + 1 < n_items ? it + 1 : it] <= j)
                             __builtin_amdgcn_sched_barrier(LD_WIDE_SCHED_MASK);
+                    });
+                    // the rows' outputs: whole 16-byte words of the drone's row where four consecutive neurons are this wavefront's
+                    static_for<r0, r1>([&](auto jc) __attribute__((always_inline)) {
+                        constexpr int j = decltype(jc)::value;
+                        if constexpr (j % 4 == 0 && j + 4 <= r1) {
+                            GeneWord<Real> o;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) o.g[q] = out[j - r0 + q];
+                            xch[lane][WP::out_word(layer) + j / 4] = o;
+                        } else if constexpr (!(j / 4 * 4 >= r0 && j / 4 * 4 + 4 <= r1)) {
+                            xf[4 * WP::out_word(layer) + j] = out[j - r0];
+                        }
                     });
                 }
                 // beside the output layer: what the next step starts from
@@ -396,7 +420,7 @@ fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __rest
         // the last step's output, as the next launch (or the drone's record) finds it
 #pragma unroll
         for (int k = 0; k < LD_N_OUTPUTS; ++k) {
-            const Real u = xch[WP::kThrustRow + k][lane];
+            const Real u = xf[4 * WP::kThrustWord + k];
             d.u[k] = dead ? d.u[k] : u;
         }
         int64_t is = i;

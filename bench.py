@@ -334,6 +334,9 @@ def main():
                     roof["levels"]["valu_issue"] = {"wave_instructions_per_launch": per["valu_wave_instructions"], "source": "PMC: SQ_INSTS_VALU",
                                                     "achieved": per["valu_wave_instructions"] / launch_s / 1e9, "peak": VALU_PEAK_GINST,
                                                     "unit": "G wave-instructions/s"}
+                if per.get("lds_busy_fraction") is not None:
+                    roof["levels"]["lds"].update(array_busy_fraction_pmc=per["lds_busy_fraction"], bank_conflict_cycles_pmc=per.get("lds_bank_conflict_cycles"),
+                                                 array_cycles_pmc=per.get("lds_array_cycles"))
                 for key in ("sq_busy_fraction", "sq_issue_fraction", "sq_wait_fraction"):
                     if per.get(key) is not None:
                         roof[key] = per[key]

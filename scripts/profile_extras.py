@@ -19,7 +19,7 @@ def last_json(path):
     return json.loads([l for l in open(path).read().splitlines() if l.startswith("{")][-1])
 
 # ---- clock of the profiled headline kernel
-rows = [r for r in load(f"{P}/c3_clock/**/*counter_collection.csv") if ("fly_split_kernel" in r["Kernel_Name"] or "fly_pair_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == "GRBM_GUI_ACTIVE"]
+rows = [r for r in load(f"{P}/c3_clock/**/*counter_collection.csv") if any(k in r["Kernel_Name"] for k in ("fly_split_kernel", "fly_pair_kernel", "fly_wide_kernel")) and r["Counter_Name"] == "GRBM_GUI_ACTIVE"]
 durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
 clocks = [float(r["Counter_Value"]) / 8 / d for r, d in zip(rows, durs)]
 un, tr = last_json(f"{P}/c3_unprofiled.json"), json.load(open(f"profiles/{R}_c3_pmc.json"))
@@ -37,9 +37,11 @@ json.dump({"round": ROUND, "what": "effective shader clock of the headline kerne
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in load(f"{P}/full_sq/**/*counter_collection.csv"):
     name = r["Kernel_Name"]
-    key = next((k for k in ("fly_pair_kernel", "fly_split_kernel", "fly_resident_kernel", "ga_breed_kernel", "ga_select_kernel", "finalize_kernel", "reset_kernel") if k in name), None)
+    key = next((k for k in ("fly_wide_kernel", "fly_pair_kernel", "fly_split_kernel", "fly_resident_kernel", "ga_breed_kernel", "ga_select_kernel", "finalize_kernel", "reset_kernel") if k in name), None)
     if key is None:
         continue
+    if key == "fly_wide_kernel":
+        key += " regs=" + name.split("fly_wide_kernel<")[1].split(",")[0].strip()
     if key == "fly_pair_kernel":
         args = name.split("fly_pair_kernel<")[1].split(",")
         key += f" keep={args[0].strip()} regs={args[1].strip()}"

@@ -20,7 +20,7 @@ ROUND=${ROUND:-3}
 for tag in c3 c3_hbm c3_tiles c3_k1 shard8 c4 c2 c5 gen12 jit12; do
   kernel=fly_          # fly_pair_kernel / fly_split_kernel / fly_step_kernel: the one with the most time in the run
   python3 scripts/profile_summary.py --out profiles/r0${ROUND}_${tag}_pmc.json --round $ROUND --kernel $kernel \
-    --trace $P/${tag}_trace --fetch $P/${tag}_fetch --write $P/${tag}_write --tcc $P/${tag}_tcc --sq $P/${tag}_sq --bench $P/${tag}_trace.json \
+    --trace $P/${tag}_trace --fetch $P/${tag}_fetch --write $P/${tag}_write --tcc $P/${tag}_tcc --sq $P/${tag}_sq --lds $P/${tag}_lds --bench $P/${tag}_trace.json \
     --cmd "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-extras${ARGS[$tag]}" \
     --pmc-cmd "rocprofv3 --pmc FETCH_SIZE (and, separately: WRITE_SIZE; TCC_HIT_sum TCC_MISS_sum; the SQ counters) --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-extras${ARGS[$tag]}"
 done

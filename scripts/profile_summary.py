@@ -9,13 +9,14 @@
 (--kernel-trace --stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE), --bench the JSON line the traced run printed.
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per 128-B request on wide coalesced
 reads, so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 is exact."""
-import argparse, csv, glob, json, statistics, sys
+import os, argparse, csv, glob, json, statistics, sys
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--out", required=True); ap.add_argument("--round", type=int, default=2)
 ap.add_argument("--kernel", required=True, help="substring of the kernel name")
 ap.add_argument("--trace"); ap.add_argument("--fetch"); ap.add_argument("--write"); ap.add_argument("--bench")
 ap.add_argument("--tcc", help="-d directory of the --pmc TCC_HIT_sum TCC_MISS_sum pass"); ap.add_argument("--sq", help="-d directory of the SQ counter pass")
+ap.add_argument("--lds", help="-d directory of the SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT pass")
 ap.add_argument("--cmd", default=""); ap.add_argument("--pmc-cmd", default="")
 a = ap.parse_args()
 
@@ -100,6 +101,15 @@ if a.sq:
         per["sq_issue_fraction"] = q.get("SQ_ACTIVE_INST_ANY", 0.0) / q["SQ_WAVE_CYCLES"]
         per["sq_wait_fraction"] = q.get("SQ_WAIT_ANY", 0.0) / q["SQ_WAVE_CYCLES"]
         per["sq_issue_stall_fraction"] = q.get("SQ_WAIT_INST_ANY", 0.0) / q["SQ_WAVE_CYCLES"]
+if a.lds and os.path.isdir(a.lds):
+    q = counter_means(a.lds)
+    if "SQ_LDS_IDX_ACTIVE" in q:
+        doc["lds_counters"] = q
+        per["lds_array_cycles"] = q["SQ_LDS_IDX_ACTIVE"]              # summed over the chip's CUs
+        per["lds_bank_conflict_cycles"] = q.get("SQ_LDS_BANK_CONFLICT")
+        if doc.get("launch_us_profiled"):
+            # share of the launch's CU-cycles (256 CUs at the nominal 2.4 GHz) in which a CU's LDS array was busy
+            per["lds_busy_fraction"] = q["SQ_LDS_IDX_ACTIVE"] / (256 * 2.4e3 * doc["launch_us_profiled"])
 doc["per_launch"] = per
 if "hbm_traffic_bytes_per_launch" in doc:
     doc["counter_note"] = ("FETCH_SIZE / WRITE_SIZE sit on the L2s' memory side: they count what the L2s pass on to the fabric, "

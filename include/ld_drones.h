@@ -335,6 +335,20 @@ int ld_fly_rollout_steps_f32(const ld_sim_params *sim, const ld_episode_params *
                              int64_t n, int32_t timesteps, int32_t steps_per_launch, int32_t waves_per_block,
                              int64_t tile_drones, void *stream);
 
+/* As ld_fly_rollout_f32, for populations in which many drones crash early (a generation of a genetic algorithm: most
+ * children crash within a few hundred timesteps, a few fly the whole episode, scattered at random over the population).
+ * fly()'s loop leaves a crashed drone alone (flight/__init__.py:80-87), but a workgroup of the fused step flies 64
+ * drones until the LAST of them has crashed.  Here the episode is flown `steps_per_launch` timesteps at a time (0 = the
+ * library's choice, 128), and before every launch a small kernel lists the drones that are still flying; the launch
+ * flies the list, 64 listed drones per workgroup (fly_wide_kernel, csrc/ld_wide.hpp, gathers their genes once per launch),
+ * so the episode costs about its live drone-steps.  `scratch`: n + 16 int32 of device memory (the list and its length;
+ * contents undefined afterwards).  Drones are independent: results are bit-identical to ld_fly_rollout_f32.  Layer specs
+ * without a fly_wide_kernel (more than 512 gene words; specs specialised at run time) take ld_fly_rollout_f32's path. */
+int ld_fly_rollout_compacting_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
+                                  const double *coins, const double *walls, const float *genomes,
+                                  float *fstate, int32_t *istate, ld_fitness_record *records,
+                                  int64_t n, int32_t timesteps, int32_t steps_per_launch, int32_t *scratch, void *stream);
+
 /* What ld_fly_rollout_f32 / ld_fly_rollout_steps_f32(..., 0, 0, 0) will launch for this spec and shard size
  * (for reporting: a benchmark states the geometry it measured): loop iterations per launch, wavefronts
  * per genome block, the number of fused-step launches of a `timesteps`-step episode, and the drones per

@@ -28,7 +28,7 @@ EXPORTS = (
     "ld_fly_rollout_resident_f32", "ld_debug_force_generic", "ld_accelerations_f32", "ld_accelerations_f64",
     "ld_fly_steps_f32", "ld_fly_rollout_steps_f32", "ld_fly_rollout_geometry_f32", "ld_fly_steps_kept_words_f32", "ld_accelerations_frames_f32", "ld_accelerations_frames_f64", "ld_fly_steps_resident_f32",
     "ld_fly_rollout_resident_f64", "ld_register_specialisation_f32", "ld_has_specialisation_f32",
-    "ld_has_resident_f32", "ld_has_resident_f64", "ld_fly_steps_auto_waves_f32", "ld_debug_lds_keep", "ld_debug_wide_plan",
+    "ld_has_resident_f32", "ld_has_resident_f64", "ld_fly_steps_auto_waves_f32", "ld_debug_lds_keep", "ld_debug_wide_plan", "ld_fly_rollout_compacting_f32",
 )
 ABI_VERSION = 3
 
@@ -99,6 +99,7 @@ def _declare(h: C.CDLL) -> None:
     h.ld_fly_steps_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, i64, i32, i32, vp]
     h.ld_fly_steps_f64.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, i64, i32, vp]
     h.ld_fly_rollout_steps_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i64, vp]
+    h.ld_fly_rollout_compacting_f32.argtypes = [sim, ep, spec, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]
     h.ld_accelerations_f32.argtypes = [sim, vp, vp, vp, vp, i64, vp]
     h.ld_accelerations_f64.argtypes = [sim, vp, vp, vp, vp, i64, vp]
     h.ld_debug_force_generic.argtypes = [C.c_int]

@@ -478,6 +478,69 @@ int rollout_steps_f32(const ld_sim_params* sim, const ld_episode_params* ep, con
     return finalize_impl<float>(ep, coins, fstate, istate, records, nullptr, n, stream);
 }
 
+// ---- rollouts that fly only the drones still flying (ld_fly_rollout_compacting_f32)
+#define LD_WIDE_LISTED_ARGS const ld_sim_params* sim, const ld_episode_params* ep, const double* coins, const double* walls, const float* genomes, \
+                            float* fstate, int32_t* istate, int64_t n, int64_t begin, int64_t end, int32_t k, hipStream_t st, const int32_t* order, const int32_t* count
+#define X(TAG) int wide_listed_##TAG(LD_WIDE_LISTED_ARGS) { return ld_u_wide_listed_f32_##TAG(sim, ep, coins, walls, genomes, fstate, istate, n, begin, end, k, st, order, count); }
+LD_FOR_EACH_KEEPING(X)
+#undef X
+int wide_listed_64_64_64(LD_WIDE_LISTED_ARGS) { return LD_ERR_SPEC; }      // (wider than 512 words: no fly_wide_kernel)
+int wide_listed_48_48(LD_WIDE_LISTED_ARGS) { return LD_ERR_SPEC; }
+int wide_listed_64_64(LD_WIDE_LISTED_ARGS) { return LD_ERR_SPEC; }
+int wide_listed_32_32_32(LD_WIDE_LISTED_ARGS) { return LD_ERR_SPEC; }
+
+// The list of a launch: indices of the drones whose status word says "not crashed", in no particular order (a wavefront
+// reserves its share of the list with one atomic add; drones are independent, so the order changes nothing).
+__global__ void __launch_bounds__(256)
+list_flying_kernel(const int32_t* __restrict__ istate, const int64_t n, int32_t* __restrict__ order, int32_t* __restrict__ count)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool flying = i < n && (istate[(int64_t)LD_I_STATUS * n + i] & 1) == 0;
+    const unsigned long long mask = __ballot(flying);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && mask) base = atomicAdd(count, __popcll(mask));
+    base = __shfl(base, 0);
+    if (flying) order[base + __popcll(mask & ((1ull << lane) - 1))] = (int32_t)i;
+}
+
+#ifndef LD_COMPACT_STEPS
+#define LD_COMPACT_STEPS 128
+#endif
+
+int rollout_compacting_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec, const double* coins,
+                           const double* walls, const float* genomes, float* fstate, int32_t* istate, ld_fitness_record* records,
+                           int64_t n, int32_t timesteps, int32_t steps_per_launch, int32_t* scratch, void* stream)
+{
+    if (timesteps < 0 || steps_per_launch < 0) return LD_ERR_SIZE;
+    int rc = check_fly_args(sim, ep, spec, coins, walls, genomes, fstate, istate, n);
+    if (rc || n == 0) return rc;
+    if (n > INT32_MAX) return LD_ERR_SIZE;
+    if (steps_per_launch == 0) steps_per_launch = LD_COMPACT_STEPS;
+    // layer specs without a fly_wide_kernel (and launches too short to keep genes): the ordinary rollout
+    if (!has_builtin_unrolled(*spec) || !flies_wide(spec, steps_per_launch))
+        return rollout_steps_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, records, n, timesteps, 0, 0, 0, stream);
+    if (!scratch) return LD_ERR_NULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int32_t* const count = scratch;                 // one word (a 64-byte line of its own), then the list
+    int32_t* const order = scratch + 16;
+    for (int32_t t = 0; t < timesteps; t += steps_per_launch) {
+        const int32_t k = timesteps - t < steps_per_launch ? timesteps - t : steps_per_launch;
+        hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t), st);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(list count)");
+        hipLaunchKernelGGL(list_flying_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, istate, n, order, count);
+        rc = check_launch("list_flying_kernel");
+        if (rc) return rc;
+        rc = LD_ERR_SPEC;
+#define X(TAG, ...)                                                                                              \
+        if (spec_is<__VA_ARGS__>(*spec)) rc = wide_listed_##TAG(sim, ep, coins, walls, genomes, fstate, istate, n, 0, n, k, st, order, count);
+        LD_FOR_EACH_UNROLLED(X)
+#undef X
+        if (rc) return rc;
+    }
+    return finalize_impl<float>(ep, coins, fstate, istate, records, nullptr, n, stream);
+}
+
 template <typename Real, bool Faithful>
 int rollout_impl(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,
                  const double* coins, const double* walls, const Real* genomes, Real* fstate, int32_t* istate,
@@ -863,6 +926,15 @@ int ld_fly_rollout_steps_f32(const ld_sim_params* sim, const ld_episode_params* 
 {
     return rollout_steps_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, records, n, timesteps, steps_per_launch,
                              waves_per_block, tile_drones, stream);
+}
+
+int ld_fly_rollout_compacting_f32(const ld_sim_params* sim, const ld_episode_params* ep, const ld_mlp_spec* spec,
+                                  const double* coins, const double* walls, const float* genomes, float* fstate,
+                                  int32_t* istate, ld_fitness_record* records, int64_t n, int32_t timesteps,
+                                  int32_t steps_per_launch, int32_t* scratch, void* stream)
+{
+    return rollout_compacting_f32(sim, ep, spec, coins, walls, genomes, fstate, istate, records, n, timesteps, steps_per_launch,
+                                  scratch, stream);
 }
 
 const char* ld_strerror(int status)

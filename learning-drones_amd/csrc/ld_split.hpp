@@ -556,3 +556,8 @@ LD_FOR_EACH_UNROLLED(LD_DECLARE_SPLIT)
 #define LD_FOR_EACH_KEEPING(X) X(8_10) X(10_10) X(16_16) X(32_32) X(16) X(32) X(64) X(8_8) X(24_24)
 #define LD_DECLARE_KEEP_WORDS(TAG) int ld_u_split_keep_words_##TAG(int32_t waves_per_block, int32_t no_pairing, int64_t*, int64_t*, int64_t*);
 LD_FOR_EACH_KEEPING(LD_DECLARE_KEEP_WORDS)
+#define LD_DECLARE_WIDE_LISTED(TAG)                                                                                   \
+    int ld_u_wide_listed_f32_##TAG(const ld_sim_params*, const ld_episode_params*, const double*, const double*,      \
+                                   const float*, float*, int32_t*, int64_t, int64_t, int64_t, int32_t, hipStream_t,   \
+                                   const int32_t*, const int32_t*);
+LD_FOR_EACH_KEEPING(LD_DECLARE_WIDE_LISTED)

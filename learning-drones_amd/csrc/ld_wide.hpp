@@ -180,8 +180,11 @@ template <int RegWords, int... H>
 __global__ void __launch_bounds__(512)
 fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __restrict__ coins, const double* __restrict__ walls,
                 const GeneWord<float>* __restrict__ genomes, float* __restrict__ fstate, int32_t* __restrict__ istate,
-                const int64_t n, const int64_t begin, const int64_t end, const int32_t n_steps)
+                const int64_t n, const int64_t begin, const int64_t end, const int32_t n_steps,
+                const int32_t* __restrict__ order, const int32_t* __restrict__ order_count)
 {
+    // order != nullptr (ld_fly_rollout_compacting_f32): lane g of the launch flies drone order[g], for the first *order_count
+    // entries of order -- the drones that were still flying when the list was made; workgroups beyond them leave at once.
     using Real = float;
     using WP = WidePlan<RegWords, H...>;
     using Plan = typename WP::Plan;
@@ -198,16 +201,19 @@ fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __rest
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t limit = order ? (int64_t)*order_count : end;
+    if (begin + (int64_t)blockIdx.x * 64 >= limit) return;    // (a listed launch covers the whole list's capacity)
     const int64_t gid = begin + (int64_t)blockIdx.x * 64 + lane;
-    const bool valid = gid < end;
-    const int64_t i = valid ? gid : end - 1;                  // tail lanes read the last drone, store nothing
+    const bool valid = gid < limit;
+    const int64_t slot = valid ? gid : limit - 1;             // tail lanes read the last drone, store nothing
+    const int64_t i = order ? (int64_t)order[slot] : slot;
 
     const int32_t status_loaded = istate[(int64_t)LD_I_STATUS * n + i];
     int32_t reward = istate[(int64_t)LD_I_REWARD * n + i];
     int32_t ncoll = istate[(int64_t)LD_I_COINS * n + i];
     DroneRegs<Real> d;
     load_drone<Real>(fstate, n, i, d);
-    const int64_t lane_offset = word_index(i, 0, Shape::W);
+    const int64_t lane_offset = word_index(i, 0, Shape::W);   // (a listed launch gathers: 64 drones of 64 different genome blocks)
     TableRegs<64 * L> table_regs;
     table_regs.load(ep, coins, walls, wave * 64 + lane);
 
@@ -445,11 +451,11 @@ inline void wide_kept_words(int64_t* lds, int64_t* regs, int64_t* streamed)
 template <int RegWords, int... H>
 int launch_fly_wide(const ld_sim_params* sim, const ld_episode_params* ep, const double* coins, const double* walls,
                     const float* genomes, float* fstate, int32_t* istate, int64_t n, int64_t begin, int64_t end,
-                    int32_t n_steps, hipStream_t stream)
+                    int32_t n_steps, hipStream_t stream, const int32_t* order = nullptr, const int32_t* order_count = nullptr)
 {
     hipLaunchKernelGGL((fly_wide_kernel<RegWords, H...>), dim3(blocks_for(end - begin, 64)), dim3(512), 0, stream,
                        make_sim<float>(*sim), make_ep<float>(*ep), coins, walls, reinterpret_cast<const GeneWord<float>*>(genomes),
-                       fstate, istate, n, begin, end, n_steps);
+                       fstate, istate, n, begin, end, n_steps, order, order_count);
     return check_launch("fly_wide_kernel");
 }
 

@@ -304,6 +304,9 @@ class Population:
         held in registers and drones handed to lane groups from a work queue (ld_fly_rollout_resident_f32);
         bit-identical results, 3-6x faster, and a population in which most drones crash early costs about
         its live drone-steps.
+        engine="compacting" (float32): the step engine flown 128 timesteps at a time over a list of the drones that are still
+        flying, re-made before every launch (ld_fly_rollout_compacting_f32): a population in which most drones crash early
+        costs about its live drone-steps, at the step engine's (lower) price per drone-step; bit-identical results.
         engine="auto": resident where available, else step."""
         if self._finalized:
             raise RuntimeError("episode already finalized; reset() first")
@@ -322,8 +325,17 @@ class Population:
             _native.check(self._fn("ld_fly_rollout_resident")(*args), "ld_fly_rollout_resident")
             self._finalized = True
             return self.records
+        if engine == "compacting":
+            if self.precision != "f32":
+                raise ValueError("engine='compacting' is a float32 engine")
+            if getattr(self, "_list_scratch", None) is None:
+                self._list_scratch = _torch().empty((self.n + 16,), dtype=_torch().int32, device=self.device)
+            args += [self.n, int(timesteps), int(steps_per_launch or 0), self._ptr(self._list_scratch), self._stream()]
+            _native.check(_native.lib().ld_fly_rollout_compacting_f32(*args), "ld_fly_rollout_compacting_f32")
+            self._finalized = True
+            return self.records
         if engine != "step":
-            raise ValueError("engine must be 'step' or 'resident'")
+            raise ValueError("engine must be 'step', 'resident', 'compacting' or 'auto'")
         if steps_per_launch is not None or waves_per_block or tile_drones is not None:
             if self.precision != "f32":
                 raise ValueError("steps_per_launch / waves_per_block / tile_drones are float32 options")

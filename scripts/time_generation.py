@@ -13,10 +13,15 @@ def sync(): torch.cuda.synchronize()
 for g in range(6):
     genes = pop.local.genomes.clone()
     out = {}
-    for name, kw in (("resident", dict(engine="resident")), ("step", dict(engine="step"))):
+    ref = None
+    for name, kw in (("resident", dict(engine="resident")), ("step", dict(engine="step")), ("compacting_64", dict(engine="compacting", steps_per_launch=64)),
+                     ("compacting_128", dict(engine="compacting")), ("compacting_256", dict(engine="compacting", steps_per_launch=256))):
+        pop.local.reset(); pop.local.fly(T, **kw); sync()                  # (warm: the first call allocates the list)
         pop.local.reset(); sync(); t0 = time.perf_counter()
         rec = pop.local.fly(T, **kw); sync()
         out[name] = round((time.perf_counter() - t0) * 1e3, 2)
+        ref = rec.clone() if ref is None else ref
+        out["same_" + name] = bool(torch.equal(ref, rec))
     life = rec[:, 1].float()
     out["live"] = round(float(life.mean()) / T, 3)
     out["waves_with_survivor"] = round(float((life.view(-1, 8).max(dim=1).values == T).float().mean()), 3)

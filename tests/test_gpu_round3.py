@@ -87,3 +87,38 @@ def test_generation_step_over_eight_ranks_is_the_single_rank_run(torch, exchange
     else:
         assert np.array_equal(got[0], want_genes[0]) and np.array_equal(order(got), order(want_genes))   # the elite keeps slot 0
     assert want_history[-1][1] >= want_history[0][1]
+
+
+def test_compacting_rollout_flies_lists_of_the_drones_still_flying(torch):
+    """ld_fly_rollout_compacting_f32 (engine="compacting"): before every launch a kernel lists the drones whose status word
+    says "not crashed" and fly_wide_kernel flies the list, 64 listed drones per workgroup, gathering their genes.  A mixed
+    population (crashes scattered through the episode, coins collected, a wall, a size that is not a multiple of 64): state,
+    bookkeeping and records equal the ordinary rollout's bit for bit, at several launch lengths, run after run; a layer spec
+    without a fly_wide_kernel takes the ordinary path and says the same."""
+    from learning_drones_amd.population import Population
+    hidden, m, T = (32, 32), 256, 700
+    n = 3 * 4096 + 64 + 29
+    genes_m, src = _replicated(hidden, m, n, seed=21)
+    walls = np.array([[3.0, 3.0, 8.0, 4.5, 7.0, 12.0]])
+    pop = Population(n, hidden, walls=walls, coins=coin_chain_reference(2))
+    pop.set_genomes(torch.as_tensor(genes_m, dtype=torch.float32, device="cuda")[torch.as_tensor(src, device="cuda")])
+    pop.fly(T)
+    want = (pop.fstate.clone(), pop.istate.clone(), pop.records.clone())
+    crashed = (want[1][2] & 1).bool()
+    assert crashed.any() and not crashed.all() and int(want[1][1].max()) >= 1
+    for kw in ({}, dict(steps_per_launch=64), dict(steps_per_launch=9), dict(steps_per_launch=T), {}):
+        pop.reset()
+        pop.fly(T, engine="compacting", **kw)
+        assert torch.equal(pop.fstate, want[0]) and torch.equal(pop.istate, want[1]) and torch.equal(pop.records, want[2]), kw
+    # an episode continued: the list is made from the status words the first half left
+    pop.reset()
+    pop.steps(300)
+    pop.fly(T - 300, engine="compacting")
+    assert torch.equal(pop.fstate, want[0]) and torch.equal(pop.records, want[2])
+    wide = Population(2048, (64, 64, 64), coins=coin_chain_reference(3))
+    wide.set_genomes(torch.as_tensor(_hover_genes((64, 64, 64), 2048, seed=3), dtype=torch.float32, device="cuda"))
+    wide.fly(150)
+    rec = wide.records.clone()
+    wide.reset()
+    wide.fly(150, engine="compacting")
+    assert torch.equal(wide.records, rec)

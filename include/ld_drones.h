@@ -275,13 +275,17 @@ int ld_fly_step_f64(const ld_sim_params *sim, const ld_episode_params *ep, const
  * state stays in registers between timesteps and the genes are re-streamed every step (from L2 /
  * Infinity Cache when the shard's genomes fit there): no per-step kernel boundary and 200/n_steps
  * instead of 200 bytes of state traffic per drone-step.  With n_steps >= 8, for nets of up to 512 gene words,
- * the workgroups of 8 wavefronts (waves_per_block 8, 11, 16, 32)
- * also KEEP 136 KiB of their drones' genes in the CU's LDS for the whole launch (loaded once, read back from LDS
- * every timestep: 31 / 41 / 63 / 100 % of a 32-32 net's genes at 64 / 48 / 32 / 16 drones per workgroup) and hold up
- * to 12-14 more gene words per wavefront in registers, so only the rest is re-streamed.  Workgroups of 32 drones
- * (waves_per_block 16) of nets with a hidden layer whose width is a multiple of 16 go further: lanes l and l + 32 of a
- * wavefront fly the same drone and sum different rows of the controller at once, and up to 32 gene-word positions per
- * wavefront (two words each) stay in registers (32-32: all of the genes on chip, 424 words in registers + 12 in LDS,
+ * the workgroups of 8 wavefronts (waves_per_block 8, 11, 16, 32) KEEP their drones' genes on chip for the whole launch
+ * (loaded once).  waves_per_block 8, one workgroup of 64 drones per block, is what the library takes wherever every gene
+ * word of 64 drones fits on chip (fly_wide_kernel, csrc/ld_wide.hpp: 38 words per wavefront in registers, the rest in LDS;
+ * 32-32: 304 + 124 words per drone, nothing re-streamed; all the shipped specs of up to 512 words fit); its timestep is
+ * rotated -- sin / cos of the angles, 1 / cos(pitch) and the coin test of the next step are computed beside the controller's
+ * output layer by the wavefronts that have no output row -- and a wavefront's rows advance together as independent chains.
+ * The other geometries (and ld_debug_lds_keep(2)) keep 136 KiB of genes per workgroup in LDS and 12-14 more words per
+ * wavefront in registers and re-stream the rest (31 / 41 / 63 / 100 % of a 32-32 net's genes in LDS at 64 / 48 / 32 / 16
+ * drones per workgroup); workgroups of 32 drones (waves_per_block 16) of nets with a hidden layer whose width is a multiple
+ * of 16 pair the halves of a wavefront: lanes l and l + 32 fly the same drone and sum different rows of the controller at
+ * once, up to 32 gene-word positions per wavefront (two words each) in registers (32-32: 424 words in registers + 12 in LDS,
  * nothing re-streamed).  ld_fly_steps_kept_words_f32 reports the split.  Results are bit-identical to n_steps
  * calls of ld_fly_step_f32 for every waves_per_block, with and without the kept genes.  ld_fly_step_f32 itself is
  * ld_fly_steps_f32(..., 1, 0, stream) for those specs. */
@@ -304,8 +308,8 @@ int ld_fly_finalize_f64(const ld_episode_params *ep, const double *coins, const 
 
 /* fly(drone, timesteps) for the whole population: the fused-step launches followed by the finalize
  * launch, all enqueued from C (no per-step host round trip); everything is ordered on `stream`: work enqueued
- * on it afterwards sees the finished episode.  64 timesteps per launch, the drone state in registers in between
- * (identical results).  _f64 and the float32 specs without an unrolled specialisation: one wavefront per genome
+ * on it afterwards sees the finished episode.  64 timesteps per launch (512 where the launches keep their genes on
+ * chip), the drone state in registers in between (identical results).  _f64 and the float32 specs without an unrolled specialisation: one wavefront per genome
  * block.  The unrolled float32 specs take ld_fly_rollout_steps_f32's default geometry.  Every launch goes to
  * `stream` (the library owns no stream), so a whole episode can be captured into a HIP graph and replayed. */
 int ld_fly_rollout_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,
@@ -318,7 +322,8 @@ int ld_fly_rollout_f64(const ld_sim_params *sim, const ld_episode_params *ep, co
                        double *distance_f64, int64_t n, int32_t timesteps, void *stream);
 
 /* As ld_fly_rollout_f32 with the launch geometry explicit: `steps_per_launch` loop iterations per
- * launch (ld_fly_steps_f32; 1 = one launch per timestep, 0 = the library's choice, 64),
+ * launch (ld_fly_steps_f32; 1 = one launch per timestep, 0 = the library's choice: 512 for launches that keep
+ * their genes on chip, 64 otherwise),
  * `waves_per_block` as in ld_fly_steps_f32, and `tile_drones` (a multiple of 64; 0 = the library's
  * choice, n = no tiling): the population is flown tile by tile, a tile's whole episode before the next
  * tile starts, so that a tile's genes -- re-streamed every timestep -- come from HBM once per episode
@@ -326,7 +331,7 @@ int ld_fly_rollout_f64(const ld_sim_params *sim, const ld_episode_params *ep, co
  * in LDS (ld_fly_steps_f32), the population's genes exceed the cache and at least 16 384 drones' genes fit in
  * ~120 MB.  Gene-keeping launches are not tiled: 256 workgroups are resident at a time, each flies all its
  * timesteps before the next takes its CU, and what the resident ones stream fits the L2s whatever the launch
- * covers (config 3: one launch of 65 536 drones per 64 timesteps, two workgroups of 8 wavefronts per block).
+ * covers (config 3: one launch of 65 536 drones per 512 timesteps, one workgroup of 8 wavefronts per block).
  * Drones are independent, so results do not depend on the tiling.  ld_fly_rollout_f32 is this with
  * (0, 0, 0) for the specs that have an unrolled specialisation; LD_ERR_SPEC for the others. */
 int ld_fly_rollout_steps_f32(const ld_sim_params *sim, const ld_episode_params *ep, const ld_mlp_spec *spec,

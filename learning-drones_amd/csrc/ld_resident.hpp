@@ -158,38 +158,43 @@ fly_resident_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __re
         if (!__any(active)) break;
 
         do {                                              // timesteps until some group needs a new drone
-        // ---- flight/__init__.py:41-52, :79 (identical to fly_step_kernel)
-        int32_t r = reward + ep.reward_time;
-        int32_t nc = ncoll;
+        // ---- flight/__init__.py:41-52, :79 (identical to fly_step_kernel).  A group whose drone has crashed (or that has no
+        // drone) sits the step out: the step is taken in place on the state (no copy committed by selects afterwards)
+        const bool stepping = active && !crashed_state;
         Real c[LD_COIN_STRIDE];
-        if (current_coin<Real>(ep, tab.coins, nc, c)) {
-            if (coin_distance<Real>(c, d.s) < c[3]) { r += (int32_t)c[4]; nc += 1; }
-        }
-        DroneRegs<Real> e = d;
         // sin / cos of roll, pitch, yaw: lanes 0, 1, 2 of the group take one angle each (the other lanes
         // compute a throw-away copy of yaw's) and the six values are read back from those lanes --
         // one sincosf per step instead of three on every lane of the group.  Same function, same inputs:
         // bit-identical to the step kernels.
-        bool crashed;
+        Real sc[6];
         if constexpr (!Faithful && L >= 4) {
             const Real angle = l == 0 ? d.s[6] : (l == 1 ? d.s[7] : d.s[8]);
-            Real sn, cs, sc[6];
+            Real sn, cs;
             Math<Real>::sincos(angle, &sn, &cs);
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 sc[2 * a] = __shfl(sn, g * L + a);
                 sc[2 * a + 1] = __shfl(cs, g * L + a);
             }
-            crashed = measure<Real, Faithful>(sim, ep, tab.walls, e, r, sc);
-        } else {
-            crashed = measure<Real, Faithful>(sim, ep, tab.walls, e, r);
         }
-        current_coin<Real>(ep, tab.coins, nc, c);
+        bool crashed = false;
+        if (stepping) {
+            int32_t r = reward + ep.reward_time;
+            if (current_coin<Real>(ep, tab.coins, ncoll, c)) {
+                if (coin_distance<Real>(c, d.s) < c[3]) { r += (int32_t)c[4]; ncoll += 1; }
+            }
+            if constexpr (!Faithful && L >= 4) crashed = measure<Real, Faithful>(sim, ep, tab.walls, d, r, sc);
+            else crashed = measure<Real, Faithful>(sim, ep, tab.walls, d, r);
+            reward = r;
+            flight_time += 1;
+            crashed_state = crashed;
+        }
+        current_coin<Real>(ep, tab.coins, ncoll, c);
 
         // ---- controller (evolve/brain.py:41-54): lane l owns neurons l, l+L, ... of every layer
         Real act[MW];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) act[k] = e.s[k];
+        for (int k = 0; k < 12; ++k) act[k] = d.s[k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) act[12 + k] = c[k];
         Real yv[(MW + L - 1) / L];                         // Dpp: this lane's outputs of the previous layer
@@ -263,20 +268,10 @@ fly_resident_kernel(const SimT<Real> sim, const EpT<Real> ep, const double* __re
         });
         if constexpr (!Dpp) LD_RES_SYNC();                 // the next step's first layer reuses buffer 0
 
-        const bool stepping = active && !crashed_state;    // commit, as fly_step_kernel does
-        if (stepping) {
+        // the controller's output acts at the next step (:89); none after a crash
+        if (stepping && !crashed) {
 #pragma unroll
-            for (int k = 0; k < 12; ++k) d.s[k] = e.s[k];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) d.acc[k] = e.acc[k];
-            if (!crashed) {
-#pragma unroll
-                for (int k = 0; k < LD_N_OUTPUTS; ++k) d.u[k] = act[k];
-            }
-            reward = r;
-            ncoll = nc;
-            flight_time += 1;
-            crashed_state = crashed;
+            for (int k = 0; k < LD_N_OUTPUTS; ++k) d.u[k] = act[k];
         }
         t_left -= 1;
 

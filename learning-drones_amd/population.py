@@ -292,18 +292,19 @@ class Population:
         """fly(drone, timesteps) for every drone, enqueued from C on the current stream.  Returns the
         device tensor of result records ([n, 4] int32 view of ld_fitness_record); see results().
 
-        engine="step": the fused step kernel, genes streamed from memory every timestep, + finalize.  By
-        default (float32, unrolled specs) a launch advances the population 64 timesteps with the drone
-        state in registers in between, and a genome block's 64 drones get as many wavefronts as fill the
-        chip; steps_per_launch / waves_per_block make that geometry explicit (ld_fly_rollout_steps_f32;
-        steps_per_launch=1 is one launch per timestep).  A population whose genes exceed the 256 MiB Infinity
-        Cache is flown tile by tile (a tile's whole episode, then the next tile), so that the re-streamed genes
-        come from the cache after a tile's first timestep (tile_drones: a multiple of 64; None = the library's
-        choice, self.n = no tiling).  Results do not depend on the geometry.
+        engine="step": the fused step kernel + finalize.  By default (float32, unrolled specs) a launch advances the
+        population 64 timesteps with the drone state in registers in between -- 512 where the launch keeps its drones' genes
+        on chip (nets of up to 512 gene words: workgroups of 64 drones, fly_wide_kernel) --, and a genome block's 64 drones
+        get as many wavefronts as fill the chip; steps_per_launch / waves_per_block make that geometry explicit
+        (ld_fly_rollout_steps_f32; steps_per_launch=1 is one launch per timestep).  A population whose genes exceed the
+        256 MiB Infinity Cache and are not kept on chip is flown tile by tile (a tile's whole episode, then the next tile), so
+        that the re-streamed genes come from the cache after a tile's first timestep (tile_drones: a multiple of 64; None = the
+        library's choice, self.n = no tiling).  Results do not depend on the geometry.
         engine="resident" (specs RESIDENT_SPECS in float32, RESIDENT_SPECS_F64 in float64): one launch for the whole episode with the genome
         held in registers and drones handed to lane groups from a work queue (ld_fly_rollout_resident_f32);
-        bit-identical results, 3-6x faster, and a population in which most drones crash early costs about
-        its live drone-steps.
+        bit-identical results; a population in which most drones crash early (a GA generation) costs about
+        its live drone-steps: there it is 1.7-2x faster than the step engine, and on a few dozen drones its one launch is
+        the shorter latency chain; a large population of drones that fly the whole episode is 1.6x faster on the step engine.
         engine="compacting" (float32): the step engine flown 128 timesteps at a time over a list of the drones that are still
         flying, re-made before every launch (ld_fly_rollout_compacting_f32): a population in which most drones crash early
         costs about its live drone-steps, at the step engine's (lower) price per drone-step; bit-identical results.

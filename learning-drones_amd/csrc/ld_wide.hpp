@@ -33,6 +33,11 @@
 #ifndef LD_WIDE_REG_WORDS
 #define LD_WIDE_REG_WORDS 38
 #endif
+// 1: the first layer's words take registers right after the output layer's (its inputs are registers, it has no LDS input
+// reads to hide a gene word's latency behind, and it starts before the LDS reads in flight have got far)
+#ifndef LD_WIDE_FIRST_LAYER_REGS
+#define LD_WIDE_FIRST_LAYER_REGS 0
+#endif
 // kept words in flight from LDS per lane
 #ifndef LD_WIDE_KEEP_DEPTH
 #define LD_WIDE_KEEP_DEPTH 4
@@ -90,15 +95,18 @@ template <int RegWords, int... H> struct WideSched {
         for (int k = 0; k < L; ++k) {
             const int len = Plan::stream_len(k);
             const int last0 = Plan::stream_pos(NL - 1, k), last_len = len - last0;
+            const int first_len = LD_WIDE_FIRST_LAYER_REGS && NL > 2 ? Plan::stream_pos(1, k) : 0;   // (a first layer that is not also the last hidden one)
             const int regs = RegWords < len ? RegWords : len;
-            const int regs_last = regs < last_len ? regs : last_len;          // the output layer's words take registers first
-            const int regs_rest = regs - regs_last, rest = last0;
+            const int regs_last = regs < last_len ? regs : last_len;          // the output layer's words take registers first,
+            const int regs_first = regs - regs_last < first_len ? regs - regs_last : first_len;      // then (LD_WIDE_FIRST_LAYER_REGS) the first layer's
+            const int regs_rest = regs - regs_last - regs_first, rest = last0 - first_len;
             t.len[k] = len;
             int n_lds = 0, n_reg = 0;
             for (int s = 0; s < len; ++s) {
                 bool reg = false;
                 if (s >= last0) reg = s - last0 < regs_last;
-                else reg = regs_rest > 0 && (long long)(s + 1) * regs_rest / rest != (long long)s * regs_rest / rest;
+                else if (s < first_len) reg = s < regs_first;
+                else reg = regs_rest > 0 && (long long)(s - first_len + 1) * regs_rest / rest != (long long)(s - first_len) * regs_rest / rest;
                 t.cls[k][s] = reg ? 1 : 0;
                 if (reg) { t.idx[k][s] = n_reg; t.pos_reg[k][n_reg++] = s; }
                 else { t.idx[k][s] = n_lds; t.pos_lds[k][n_lds++] = s; }
@@ -346,12 +354,7 @@ fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __rest
                 // word m of this layer's inputs: the post-step state and the coin (first layer), or the previous layer's outputs in LDS
                 auto fetch = [&](auto mc) __attribute__((always_inline)) {
                     constexpr int m = decltype(mc)::value;
-                    if constexpr (layer == 0) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) aw[m % (AW / 4)].g[q] = 4 * m + q < 12 ? d.s[4 * m + q < 12 ? 4 * m + q : 0] : c[4 * m + q < 15 ? 4 * m + q - 12 : 0];
-                    } else {
-                        aw[m % (AW / 4)] = xch[lane][in_word + m];
-                    }
+                    if constexpr (layer > 0) aw[m % (AW / 4)] = xch[lane][in_word + m];
                 };
                 constexpr int in_words = (n_in + 3) / 4;
                 if constexpr (r1 > r0) {
@@ -373,10 +376,12 @@ fly_wide_kernel(const SimT<float> sim, const EpT<float> ep, const double* __rest
                             constexpr int p = 4 * w + cidx;
                             if constexpr (p >= g0 && p < g1) {
                                 constexpr int k = p - g0;
-                                if constexpr (k == 0) {
-                                    acc[j - r0] = mac<Real, true>(v.g[cidx], aw[0].g[0], (Real)0);
-                                } else if constexpr (k < n_in) {
-                                    acc[j - r0] = mac<Real, true>(v.g[cidx], aw[(k / 4) % (AW / 4)].g[k % 4], acc[j - r0]);
+                                if constexpr (k < n_in) {
+                                    // input k: straight from the state registers in the first layer, from the window otherwise
+                                    Real x;
+                                    if constexpr (layer == 0) x = k < 12 ? d.s[k < 12 ? k : 0] : c[k >= 12 ? k - 12 : 0];
+                                    else x = aw[(k / 4) % (AW / 4)].g[k % 4];
+                                    acc[j - r0] = mac<Real, true>(v.g[cidx], x, k == 0 ? (Real)0 : acc[j - r0]);
                                 } else {
                                     const Real sum = acc[j - r0] + v.g[cidx];
                                     out[j - r0] = last ? sigmoid04<Real>(sum) : relu<Real>(sum);

@@ -496,6 +496,7 @@ def main():
     from learning_drones_amd.parallel import DeviceEvolution
     evo = DeviceEvolution(pop, seed=0x1D20, exchange=args.exchange)
     n_gen, gen_live, gen_dt, gen_error = 3, 0.0, float("nan"), ("skipped (--no-extras)" if args.no_extras else None)
+    steady_live, steady_dt = 0.0, float("nan")
     if not args.no_extras:
         ok = 1
         try:
@@ -508,6 +509,17 @@ def main():
                 gen_live += float(rec[:, 1].double().sum().item()) / (rec.shape[0] * T) / n_gen
             fence()
             gen_dt = max_over_ranks(time.perf_counter() - g0)
+            # ... and the same loop once the population is the GA's own (four more generations on, then six timed): the
+            # first generations above still carry the hand-made stable flyers' long-lived children
+            for _ in range(4):
+                evo.step(T)
+            fence()
+            g1 = time.perf_counter()
+            for _ in range(6):
+                _, _, rec = evo.step(T)
+                steady_live += float(rec[:, 1].double().sum().item()) / (rec.shape[0] * T) / 6
+            fence()
+            steady_dt = max_over_ranks(time.perf_counter() - g1)
         except RuntimeError as err:      # reported, and fatal for the whole job below (no rank may carry on alone)
             gen_error, ok = str(err)[:200], 0
         if dist:                         # every rank learns whether ANY rank failed: nobody carries on alone
@@ -567,6 +579,10 @@ def main():
                            "exchange": evo.exchange if world > 1 else "local",
                            "exchange_bytes_per_generation_per_rank": evo.exchange_bytes(),
                            "live_drone_step_fraction": gen_live, "error": gen_error,
+                           "steady_state": None if gen_error else {
+                               "generations_per_s": 6 / steady_dt, "measured": 6, "after_generations": 8, "live_drone_step_fraction": steady_live,
+                               "note": "the same loop from the ninth generation on: generations_per_s above is quoted on the first "
+                                       "three generations after the hand-made stable flyers (comparable across rounds)"},
                            "select_breed_ms": breed_ms, "select_breed_gbs": breed_gbs,
                            "select_breed_note": "gather of 16-byte parent words at random drone indices + streaming "
                                                 "child stores; algorithmic 8P bytes per drone"},

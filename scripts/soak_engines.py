@@ -32,7 +32,8 @@ for r in range(rounds):
     tile = int(rng.choice([64, 128, 192, 1024, 4096]))
     out = []
     f64 = hidden in Population.RESIDENT_SPECS_F64 and rng.random() < 0.25
-    for kw in ("generic", dict(), dict(steps_per_launch=k, waves_per_block=waves, tile_drones=tile), dict(engine="resident")):
+    for kw in ("generic", dict(), dict(steps_per_launch=k, waves_per_block=waves, tile_drones=tile), dict(engine="resident"),
+               dict(engine="compacting", steps_per_launch=int(rng.choice([0, 8, 50, 300])))):
         pop = Population(n, hidden, coins=coins, walls=walls, init_state=init, coin_respawn=respawn, sim=sim)
         pop.set_genomes(genes)
         if kw == "generic":
